@@ -1,0 +1,197 @@
+/* seeme_hip.h -- C-ABI of libseeme_hip.so: MI355X (gfx950) kernels for the SEE-ME
+ * motion-latent-diffusion hot path.
+ *
+ * The reference (L-Scofano/SEEME) is pure Python/PyTorch and has no FFI boundary of its own
+ * (SURVEY.md F1); its plug-in boundary is instantiate_from_config(cfg) in mld/config.py:25-32.
+ * This header is therefore the *build-side* boundary proposed in SURVEY.md section 8(b): plain
+ * pointers and sizes, no torch types.  Each entry point names the reference code it replaces.
+ * The Python classes in seeme_amd/ (same constructor kwargs / methods / state_dict keys as the
+ * reference classes) are the only callers; see INTEGRATION.md for the ctypes binding.
+ *
+ * Conventions
+ *   - all tensor arguments are DEVICE pointers to contiguous fp32 (unless stated), row-major;
+ *   - every function enqueues work on `stream` (a hipStream_t passed as void*) and returns
+ *     without synchronising; no allocation, no host sync inside (hipGraph-capturable);
+ *   - return value 0 = ok, non-zero = error; seeme_last_error() gives a thread-local message;
+ *   - workspaces are caller-allocated device buffers; *_workspace_bytes() gives the size.
+ */
+#ifndef SEEME_HIP_H
+#define SEEME_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEEME_D 256        /* latent_dim[-1]; every config of the reference uses 256 */
+#define SEEME_NLAYERS 5    /* VAE: hard-coded mld_vae.py:51; denoiser: configs/modules/denoiser.yaml:6 */
+
+enum { SEEME_ACT_NONE = 0, SEEME_ACT_RELU = 1, SEEME_ACT_GELU = 2, SEEME_ACT_SILU = 3 };
+enum { SEEME_SCHED_NONE = 0, SEEME_SCHED_DDIM = 1, SEEME_SCHED_DDPM = 2 };
+
+int seeme_version(void);
+const char* seeme_last_error(void);
+
+/* ------------------------------------------------------------------ generic fused linear
+ * Y[M,N] = LN?( act( pre(A)[M,K] @ W[N,K]^T + bias ) + res )
+ * Replaces torch.nn.functional.linear (+ fused neighbours) wherever the path uses it, e.g.
+ * skel_embedding mld_vae.py:147, final_layer :251, skip Linear(2D,D) cross_attention.py:58-60
+ * (A | A2 concatenation without materialising it), ResnetBlockFC respointnet.py:88-97.
+ * K may be any size: W rows must be readable for roundup16(K) floats (zero padded) -- ldw says so. */
+typedef struct {
+    const float* A;  int lda;         /* [M, K1] */
+    const float* A2; int lda2;        /* optional [M, K-K1] (concat along K); NULL if unused */
+    int K1;
+    const float* W;  int ldw;         /* [N, >=roundup16(K)] */
+    const float* bias;                /* [N] or NULL */
+    const float* res; int ldr;        /* optional residual [M,N] added after act */
+    const float* ln_w; const float* ln_b;          /* optional LayerNorm over N (N must be <= 256) */
+    const float* pre_ln_w; const float* pre_ln_b;  /* optional LayerNorm over K applied to A rows first */
+    float* Y; int ldy;
+    int M, N, K;
+    int pre_act;                      /* activation applied to A (after pre-LN), SEEME_ACT_* */
+    int act;                          /* activation applied to the product */
+    float eps;
+} SeemeLinearArgs;
+int seeme_linear(const SeemeLinearArgs* args, void* stream);
+
+/* ------------------------------------------------------------------ Transformer VAE
+ * Weights of mld.models.architectures.mld_vae.MldVae (state_dict names in comments,
+ * SURVEY.md App. A).  All fp32 device pointers in PyTorch layout ([out,in]). */
+typedef struct {
+    const float *in_w, *in_b;       /* self_attn.in_proj_weight [768,256], in_proj_bias */
+    const float *out_w, *out_b;     /* self_attn.out_proj.{weight,bias} */
+    const float *l1_w, *l1_b;       /* linear1 [ff,256] */
+    const float *l2_w, *l2_b;       /* linear2 [256,ff] */
+    const float *n1_w, *n1_b, *n2_w, *n2_b;
+    /* decoder layers only (TransformerDecoderLayer, cross_attention.py:319-367); NULL in encoder */
+    const float *ca_in_w, *ca_in_b; /* multihead_attn.in_proj_* */
+    const float *ca_out_w, *ca_out_b;
+    const float *n3_w, *n3_b;
+} SeemeXfLayer;
+
+typedef struct {
+    SeemeXfLayer layer[SEEME_NLAYERS];   /* input_blocks.0, .1, middle_block, output_blocks.0, .1 */
+    const float *skip_w[2], *skip_b[2];  /* linear_blocks.{0,1} [256,512] */
+    const float *norm_w, *norm_b;        /* stack-final LayerNorm */
+} SeemeSkipStack;
+
+typedef struct {
+    int nfeats;                 /* F */
+    int ff;                     /* 128 (hard-coded mld_vae.py:53) */
+    const float* token;         /* global_motion_token [2,256] */
+    const float* pe_enc;        /* query_pos_encoder.pe [500,1,256] */
+    const float* pe_dec;        /* query_pos_decoder.pe */
+    const float* emb_w; int emb_ldw; /* skel_embedding.weight [256, roundup16(F)] zero-padded copy */
+    const float* emb_b;
+    const float* fin_w;         /* final_layer.weight [F,256] */
+    const float* fin_b;
+    SeemeSkipStack enc, dec;
+} SeemeVaeWeights;
+
+size_t seeme_vae_workspace_bytes(int B, int T);
+
+/* MldVae.encode (mld_vae.py:128-193) up to the posterior parameters:
+ * features [B,T,F], lengths [B] (int32, device) -> mu [B,256], logvar [B,256]
+ * (the caller forms std = exp(logvar)^0.5 and the Normal; rsample is RNG, host side). */
+int seeme_vae_encode(const SeemeVaeWeights* w, const float* features, const int32_t* lengths,
+                     int B, int T, float* mu, float* logvar, void* workspace, size_t ws_bytes, void* stream);
+
+/* MldVae.decode, arch encoder_decoder (mld_vae.py:195-256): z [B,256], lengths -> feats [B,T,F]
+ * (padded frames not zeroed, as in the reference :253). */
+int seeme_vae_decode(const SeemeVaeWeights* w, const float* z, const int32_t* lengths,
+                     int B, int T, float* feats, void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ denoiser + sampling loop
+ * mld.models.architectures.mld_denoiser.MldDenoiser (arch trans_enc, MD_TRANS layers
+ * mdiff_transformer.py:257-304) and MLD._diffusion_reverse (mld/models/modeltype/mld.py:432-511).
+ *
+ * Weight image: the host packs the state_dict once into
+ *   wg : GEMV-layout matrices, element type fp32 or bf16 (wdtype 0 / 1); a [N,K] PyTorch matrix is
+ *        stored as [K/KV][N][KV] with KV = 4 (fp32) or 8 (bf16) so that a wave reads 1 KiB contiguous;
+ *   vp : fp32 vectors (biases, LayerNorm params, pe row 0);
+ * in the order documented in seeme_amd/csrc/den_layout.h (mirrored by seeme_amd/_pack.py).
+ */
+typedef struct {
+    const void*  wg;   int wdtype;       /* 0 = fp32, 1 = bf16 */
+    const float* vp;
+    int nhead;                           /* 1, 2 or 4 */
+    int ff_sa;                           /* 1024 (hard-coded mdiff_transformer.py:279) */
+    int ff;                              /* 128 */
+    /* PyTorch-layout fp32 tensors used by the per-call table builders */
+    const float* kv_cat_w; const float* kv_cat_b;       /* [5*512,256]: sa in_proj K|V rows per layer */
+    const float* style_cat_w; const float* style_cat_b; /* [5*1024,256]: ca emb_layers.1 | ffn emb_layers.1 */
+    const float* time_w1; const float* time_b1; const float* time_w2; const float* time_b2;
+    const float* ca_kv_w[SEEME_NLAYERS]; const float* ca_kv_b[SEEME_NLAYERS];   /* [512,256] key|value per layer */
+    const float* ca_tn_w[SEEME_NLAYERS]; const float* ca_tn_b[SEEME_NLAYERS];   /* ca_block.text_norm */
+} SeemeDenoiserWeights;
+
+/* per-row time tables: floats per row = 5*512 (sa K|V of the time token) + 5*1024 (AdaLN scale|shift, ca|ffn) */
+#define SEEME_TROW 7680
+/* per-sample condition tables: floats per (sample, token) = 5 layers * (sa K|V 512 + ca key|value 512) */
+#define SEEME_CROW 5120
+
+size_t seeme_denoiser_workspace_bytes(int n_rows, int B, int N);
+
+/* Build the time tables for `n_rows` timestep feature rows tfeat [n_rows,256] (sinusoidal features,
+ * tools/embeddings.py:245-285, computed by the host) -> ttab [n_rows, SEEME_TROW].
+ * Batch-invariant in sampling. */
+int seeme_denoiser_time_tables(const SeemeDenoiserWeights* w, const float* tfeat, int n_rows,
+                               float* ttab, void* workspace, size_t ws_bytes, void* stream);
+
+/* Build the per-sample condition tables for cond [Bc,N,256] (batch-first) -> ctab [Bc,N,SEEME_CROW]
+ * (step-invariant K/V of the condition tokens). */
+int seeme_denoiser_cond_tables(const SeemeDenoiserWeights* w, const float* cond, int Bc, int N,
+                               float* ctab, void* workspace, size_t ws_bytes, void* stream);
+
+typedef struct {
+    int B;                 /* samples (latents rows) */
+    int N;                 /* condition tokens per sample */
+    int steps;             /* loop iterations (1 for a plain forward) */
+    int sched;             /* SEEME_SCHED_* ; NONE: out = eps of the single step */
+    int cfg;               /* 1: ctab holds 2B samples (uncond first, mld.py:489) and guidance is applied */
+    float guidance_scale;
+    const float* latents;  /* [B,256] initial */
+    const float* ctab;     /* [B or 2B, N, SEEME_CROW] */
+    const float* ttab;     /* [rows, SEEME_TROW] */
+    const int32_t* trow;   /* sampling: [steps] row of ttab per step; forward: [B] row per sample */
+    int trow_per_sample;   /* 0: trow[step], 1: trow[b] */
+    const float* coef;     /* [steps,8] scheduler scalars per step (see seeme_amd/schedulers.py) */
+    const float* noise;    /* optional [steps,B,256] step noise (eta>0 / DDPM), NULL otherwise */
+    float* out;            /* [B,256] */
+} SeemeSampleArgs;
+
+int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeSampleArgs* a, void* stream);
+
+/* ------------------------------------------------------------------ SMPL linear blend skinning
+ * smplx.SMPL.forward (call sites mld/models/modeltype/mld.py:764-770 ...). */
+typedef struct {
+    int V;                        /* 6890 */
+    const float* v_template;      /* [V,3] (flat [V*3] = bias of the blend GEMM) */
+    const float* blend_w;         /* [V*3, 224]: cols 0..9 shapedirs, 10..216 posedirs^T, 217..223 zero */
+    const float* lbs_weights;     /* [V,24] */
+    const float* J_template;      /* [24,3]  = J_regressor @ v_template      (precomputed) */
+    const float* J_shapedirs;     /* [24,3,10] = J_regressor @ shapedirs */
+    const int32_t* parents;       /* [24] kinematic tree, parents[0] = -1 */
+    /* compact copy of the model restricted to the 21 extra-joint vertices (smplx VertexJointSelector) */
+    const float* ex_template;     /* [21,3] */
+    const float* ex_shapedirs;    /* [21*3,10] */
+    const float* ex_posedirs;     /* [207, 63] */
+    const float* ex_weights;      /* [21,24] */
+} SeemeSmplModel;
+
+size_t seeme_smpl_workspace_bytes(int M);
+
+/* pose: axis-angle [M,72] (pose2rot=True) or rotation matrices [M,24,9]; betas [M,10]; transl [M,3] or NULL.
+ * joints [M,45,3] (24 posed joints + 21 vertex-picked joints); vertices [M,V,3] or NULL (joints-only
+ * fast path: no mesh is formed). */
+int seeme_smpl_lbs(const SeemeSmplModel* m, const float* betas, const float* pose, int pose_is_rotmat,
+                   const float* transl, int M, float* joints, float* vertices,
+                   void* workspace, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEEME_HIP_H */

@@ -1,0 +1,138 @@
+"""ctypes binding of libseeme_hip.so (the C-ABI declared in include/seeme_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails the caller gets an
+exception.  The structures below mirror the header field by field.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libseeme_hip.so")
+
+NLAYERS = 5
+TROW = 7680
+CROW = 5120
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
+SCHED_NONE, SCHED_DDIM, SCHED_DDPM = 0, 1, 2
+
+fp = C.c_void_p  # device pointers travel as integers
+
+
+class SeemeError(RuntimeError):
+    pass
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [("A", fp), ("lda", C.c_int), ("A2", fp), ("lda2", C.c_int), ("K1", C.c_int),
+                ("W", fp), ("ldw", C.c_int), ("bias", fp), ("res", fp), ("ldr", C.c_int),
+                ("ln_w", fp), ("ln_b", fp), ("pre_ln_w", fp), ("pre_ln_b", fp),
+                ("Y", fp), ("ldy", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("pre_act", C.c_int), ("act", C.c_int), ("eps", C.c_float)]
+
+
+class XfLayer(C.Structure):
+    _fields_ = [(n, fp) for n in ("in_w", "in_b", "out_w", "out_b", "l1_w", "l1_b", "l2_w", "l2_b",
+                                  "n1_w", "n1_b", "n2_w", "n2_b",
+                                  "ca_in_w", "ca_in_b", "ca_out_w", "ca_out_b", "n3_w", "n3_b")]
+
+
+class SkipStack(C.Structure):
+    _fields_ = [("layer", XfLayer * NLAYERS), ("skip_w", fp * 2), ("skip_b", fp * 2),
+                ("norm_w", fp), ("norm_b", fp)]
+
+
+class VaeWeights(C.Structure):
+    _fields_ = [("nfeats", C.c_int), ("ff", C.c_int), ("token", fp), ("pe_enc", fp), ("pe_dec", fp),
+                ("emb_w", fp), ("emb_ldw", C.c_int), ("emb_b", fp), ("fin_w", fp), ("fin_b", fp),
+                ("enc", SkipStack), ("dec", SkipStack)]
+
+
+class DenoiserWeights(C.Structure):
+    _fields_ = [("wg", fp), ("wdtype", C.c_int), ("vp", fp), ("nhead", C.c_int), ("ff_sa", C.c_int),
+                ("ff", C.c_int), ("kv_cat_w", fp), ("kv_cat_b", fp), ("style_cat_w", fp), ("style_cat_b", fp),
+                ("time_w1", fp), ("time_b1", fp), ("time_w2", fp), ("time_b2", fp),
+                ("ca_kv_w", fp * NLAYERS), ("ca_kv_b", fp * NLAYERS),
+                ("ca_tn_w", fp * NLAYERS), ("ca_tn_b", fp * NLAYERS)]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("N", C.c_int), ("steps", C.c_int), ("sched", C.c_int), ("cfg", C.c_int),
+                ("guidance_scale", C.c_float), ("latents", fp), ("ctab", fp), ("ttab", fp), ("trow", fp),
+                ("trow_per_sample", C.c_int), ("coef", fp), ("noise", fp), ("out", fp)]
+
+
+class SmplModel(C.Structure):
+    _fields_ = [("V", C.c_int), ("v_template", fp), ("blend_w", fp), ("lbs_weights", fp), ("J_template", fp),
+                ("J_shapedirs", fp), ("parents", fp), ("ex_template", fp), ("ex_shapedirs", fp),
+                ("ex_posedirs", fp), ("ex_weights", fp)]
+
+
+# name -> (restype, argtypes); every symbol of include/seeme_hip.h
+_SIGNATURES = {
+    "seeme_version": (C.c_int, []),
+    "seeme_last_error": (C.c_char_p, []),
+    "seeme_linear": (C.c_int, [C.POINTER(LinearArgs), fp]),
+    "seeme_vae_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "seeme_vae_encode": (C.c_int, [C.POINTER(VaeWeights), fp, fp, C.c_int, C.c_int, fp, fp, fp, C.c_size_t, fp]),
+    "seeme_vae_decode": (C.c_int, [C.POINTER(VaeWeights), fp, fp, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
+    "seeme_denoiser_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "seeme_denoiser_time_tables": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, fp, fp, C.c_size_t, fp]),
+    "seeme_denoiser_cond_tables": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
+    "seeme_denoiser_sample": (C.c_int, [C.POINTER(DenoiserWeights), C.POINTER(SampleArgs), fp]),
+    "seeme_den_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "seeme_smpl_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "seeme_smpl_lbs": (C.c_int, [C.POINTER(SmplModel), fp, fp, C.c_int, fp, C.c_int, fp, fp, fp, C.c_size_t, fp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raises SeemeError when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SeemeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or seeme_amd/csrc/build.sh.  There is no CPU / PyTorch fallback for this path.")
+        try:
+            l = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise SeemeError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGNATURES.items():
+            f = getattr(l, name)  # AttributeError if the library does not export a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().seeme_last_error().decode("utf-8", "replace")
+        raise SeemeError(f"{what or 'seeme_hip'} failed (rc={rc}): {msg}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(t, name: str):
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise SeemeError(f"{name} must be a tensor on the ROCm device (cuda:N); this path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise SeemeError(f"{name} must be float32, got {t.dtype}")

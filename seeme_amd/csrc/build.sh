@@ -1,0 +1,10 @@
+#!/bin/bash
+# Build libseeme_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+out="$here/../libseeme_hip.so"
+srcs=("$here"/api.hip "$here"/vae_kernels.hip "$here"/den_kernels.hip)
+[ -f "$here/smpl_kernels.hip" ] && srcs+=("$here/smpl_kernels.hip")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
+    -Wall -Wno-unused-function -o "$out" "${srcs[@]}" "$@"
+echo "built $out"

@@ -1,0 +1,153 @@
+// common.hpp -- device helpers shared by the gfx950 kernels (wave64, MFMA f32 tiles, LDS row ops).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/seeme_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SEEME_WAVE 64
+#define TILE_M 32          // rows per workgroup in the row-tile kernels (2 MFMA m-tiles)
+#define LDS_PAD 8          // floats; row stride K+8 makes the ds_read_b128 A-fragment reads conflict-free
+#define CH_N 256           // output columns per workgroup pass (4 waves x 4 n-tiles x 16)
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case SEEME_ACT_RELU: return fmaxf(v, 0.f);
+        case SEEME_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case SEEME_ACT_SILU: return v / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 MFMA row-tile GEMM:  acc[mt][nt] += A[MTL*16 rows, K] * W[n, K]^T
+//   A  : LDS, row stride lda floats (lda % 4 == 0), K = 16*K16 columns, zero padded
+//   W  : global, row-major [*, ldw]; this wave's columns are n0 + nt*16 + (lane&15), clamped to
+//        n_valid-1 for the loads (results for n >= n_valid are discarded by the caller)
+// v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; here the 16 k of a
+// block are permuted (k = 4*(l>>4)+j for step j) so that each lane reads 4 contiguous floats.
+// Accumulator: lane holds col = lane&15, rows 4*(lane>>4)+reg (cdna_hip_programming.md section 3).
+template <int MTL, int NTL>
+__device__ __forceinline__ void tile_gemm_f32(const float* __restrict__ As, int lda,
+                                              const float* __restrict__ W, int ldw,
+                                              int n0, int n_valid, int K16,
+                                              f32x4 (&acc)[MTL][NTL]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+    const float* wp[NTL];
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        int n = n0 + nt * 16 + r;
+        n = n < n_valid ? n : n_valid - 1;
+        wp[nt] = W + (size_t)n * ldw + 4 * kq;
+    }
+    const float* ap = As + r * lda + 4 * kq;
+    for (int kb = 0; kb < K16; ++kb) {
+        float4 a[MTL], b[NTL];
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) b[nt] = *reinterpret_cast<const float4*>(wp[nt] + kb * 16);
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+            }
+    }
+}
+
+// Same, but the B operand is a "value" matrix V[k][n] (contraction index on the ROWS of V):
+// acc += A[., K] * V[K, n]; rows clamped to k_valid-1 (the matching A columns must be zero).
+template <int MTL, int NTL>
+__device__ __forceinline__ void tile_gemm_f32_kn(const float* __restrict__ As, int lda,
+                                                 const float* __restrict__ V, int ldv,
+                                                 int n0, int k_valid, int K16,
+                                                 f32x4 (&acc)[MTL][NTL]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+    const float* ap = As + r * lda + 4 * kq;
+    const float* vp = V + n0 + r;
+    for (int kb = 0; kb < K16; ++kb) {
+        float4 a[MTL];
+        float b[NTL][4];
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int k = kb * 16 + 4 * kq + j;
+            k = k < k_valid ? k : k_valid - 1;
+            const float* row = vp + (size_t)k * ldv;
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) b[nt][j] = row[nt * 16];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt][0], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt][1], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt][2], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt][3], acc[mt][nt], 0, 0, 0);
+            }
+    }
+}
+
+template <int MTL, int NTL>
+__device__ __forceinline__ void acc_zero(f32x4 (&acc)[MTL][NTL]) {
+#pragma unroll
+    for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// Store a wave's accumulators into an LDS tile Cs[row][c0 + nt*16 + (lane&15)] (+bias, act).
+// c0 = this wave's first column INSIDE the tile; gcol0 = global column of tile column 0 (for bias).
+template <int MTL, int NTL>
+__device__ __forceinline__ void acc_store_lds(const f32x4 (&acc)[MTL][NTL], float* __restrict__ Cs, int ldc,
+                                              int c0, const float* __restrict__ bias, int gcol0, int n_valid,
+                                              int act) {
+    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int c = c0 + nt * 16 + r;
+        const int g = gcol0 + c;
+        const float bv = (bias != nullptr && g < n_valid) ? bias[g] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = mt * 16 + 4 * kq + i;
+                Cs[row * ldc + c] = act_apply(acc[mt][nt][i] + bv, act);
+            }
+    }
+}
+
+// LayerNorm of one 256-wide row held 4 floats per lane by a full wave (two-pass, torch semantics).
+__device__ __forceinline__ float4 wave_layernorm256(float4 v, const float* __restrict__ w,
+                                                    const float* __restrict__ b, float eps) {
+    const int lane = threadIdx.x & 63;
+    float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+    float4 c = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+    float var = wave_sum(c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) * (1.f / 256.f);
+    float rs = 1.f / sqrtf(var + eps);
+    const float4 wv = *reinterpret_cast<const float4*>(w + lane * 4);
+    const float4 bv = *reinterpret_cast<const float4*>(b + lane * 4);
+    return make_float4(c.x * rs * wv.x + bv.x, c.y * rs * wv.y + bv.y, c.z * rs * wv.z + bv.z,
+                       c.w * rs * wv.w + bv.w);
+}

@@ -1,0 +1,329 @@
+"""MldDenoiser -- drop-in for ``mld.models.architectures.mld_denoiser.MldDenoiser``
+(reference mld_denoiser.py:18-244, layer mdiff_transformer.py:257-304).
+
+Same constructor arguments, ``forward(sample, timestep, encoder_hidden_states, lengths)`` signature
+and layouts (condition **seq-first** [N,B,256]), same ``state_dict`` keys.
+The arithmetic runs in libseeme_hip.so; on top of the reference surface there is ``sample_loop``:
+the whole reverse-diffusion loop of MLD._diffusion_reverse (mld.py:467-497) as ONE kernel launch.
+
+``target: seeme_amd.mld_denoiser.MldDenoiser`` in configs/modules/denoiser.yaml selects it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .mld_vae import _PositionEmbeddingLearned1D, _EncoderLayerParams, _SkipStackParams, _param_fingerprint
+
+_LAYER_FIELDS = ["skip", "inp", "outp", "l1", "l2", "caq", "cao", "f1", "f2", "fo",
+                 "skip_b", "in_b", "out_b", "n1w", "n1b", "l1b", "l2b", "n2w", "n2b", "cnw", "cnb", "caq_b",
+                 "csnw", "csnb", "cao_b", "f1b", "f2b", "fsnw", "fsnb", "fo_b"]
+
+
+def timestep_features(timesteps: torch.Tensor, dim: int = 256, flip_sin_to_cos: bool = True,
+                      freq_shift: float = 0.0, max_period: int = 10000) -> torch.Tensor:
+    """Sinusoidal timestep features, tools/embeddings.py:245-285 (host-side plumbing: a [rows,256]
+    table; evaluated with torch on whatever device `timesteps` lives on)."""
+    assert timesteps.dim() == 1
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32, device=timesteps.device)
+    exponent = exponent / (half - freq_shift)
+    emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    if dim % 2 == 1:
+        emb = torch.nn.functional.pad(emb, (0, 1, 0, 0))
+    return emb
+
+
+class _TimestepEmbeddingParams(nn.Module):
+    def __init__(self, channel, time_embed_dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(channel, time_embed_dim)
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+
+class _StylizationParams(nn.Module):
+    """mdiff_transformer.py:137-150 (indices 1 / 2 of the Sequentials carry the Linear layers)."""
+
+    def __init__(self, d, t):
+        super().__init__()
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(t, 2 * d))
+        self.norm = nn.LayerNorm(d)
+        self.out_layers = nn.Sequential(nn.SiLU(), nn.Dropout(p=0.0), nn.Linear(d, d))
+
+
+class _CrossAttnParams(nn.Module):
+    def __init__(self, d, t):
+        super().__init__()
+        self.norm = nn.LayerNorm(d)
+        self.text_norm = nn.LayerNorm(d)
+        self.query = nn.Linear(d, d)
+        self.key = nn.Linear(d, d)
+        self.value = nn.Linear(d, d)
+        self.proj_out = _StylizationParams(d, t)
+
+
+class _FFNParams(nn.Module):
+    def __init__(self, d, ff, t):
+        super().__init__()
+        self.linear1 = nn.Linear(d, ff)
+        self.linear2 = nn.Linear(ff, d)
+        self.proj_out = _StylizationParams(d, t)
+
+
+class _MDLayerParams(nn.Module):
+    """LinearTemporalDiffusionTransformerDecoderLayer (mdiff_transformer.py:257-284): registration
+    order ca_block, ffn, sa_block as in the reference; sa_block ff is hard-coded 1024/relu (:279)."""
+
+    def __init__(self, d, ff, nhead, dropout):
+        super().__init__()
+        self.d_model = d
+        self.ca_block = _CrossAttnParams(d, d)
+        self.ffn = _FFNParams(d, ff, d)
+        self.sa_block = _EncoderLayerParams(d, nhead, 1024, dropout)
+
+
+class MldDenoiser(nn.Module):
+
+    def __init__(self,
+                 ablation,
+                 nfeats: int = 72,
+                 condition: str = "text",
+                 latent_dim: list = [1, 256],
+                 ff_size: int = 128,
+                 num_layers: int = 6,
+                 num_heads: int = 4,
+                 dropout: float = 0.1,
+                 normalize_before: bool = False,
+                 activation: str = "gelu",
+                 flip_sin_to_cos: bool = True,
+                 return_intermediate_dec: bool = False,
+                 position_embedding: str = "learned",
+                 arch: str = "trans_enc",
+                 freq_shift: int = 0,
+                 guidance_scale: float = 7.5,
+                 guidance_uncondp: float = 0.1,
+                 text_encoded_dim: int = 256,
+                 nclasses: int = 10,
+                 weight_dtype: str = "fp32",
+                 **kwargs) -> None:
+        super().__init__()
+        self.latent_dim = latent_dim[-1]
+        self.text_encoded_dim = text_encoded_dim
+        self.condition = condition
+        self.arch = arch
+        self.pe_type = ablation.DIFF_PE_TYPE
+        self.MD_trans = ablation.MD_TRANS
+        self.flip_sin_to_cos, self.freq_shift = flip_sin_to_cos, freq_shift
+        self.num_heads, self.ff_size, self.num_layers = num_heads, ff_size, num_layers
+        if "text" not in self.condition:
+            raise TypeError(f"condition type {self.condition} not supported")      # mld_denoiser.py:190
+        if self.pe_type != "mld":
+            if self.pe_type == "actor":
+                raise NotImplementedError("DIFF_PE_TYPE 'actor' is outside the accelerated path")
+            raise ValueError("Not Support PE type")                                # :96
+        if arch != "trans_enc":
+            if arch == "trans_dec":
+                raise NotImplementedError("arch 'trans_dec' is outside the accelerated path")
+            raise ValueError(f"Not supported architechure{self.arch}!")            # :149
+        if ablation.VAE_TYPE == "no" or not ablation.SKIP_CONNECT or not self.MD_trans:
+            raise NotImplementedError("accelerated path: VAE latent + SKIP_CONNECT + MD_TRANS (all SEE-ME configs)")
+        if text_encoded_dim != self.latent_dim or self.latent_dim != 256 or latent_dim[0] != 1 or num_layers != 5:
+            raise NotImplementedError("accelerated path: latent_dim [1,256], text_encoded_dim 256, 5 layers")
+        if num_heads not in (1, 2, 4):
+            raise NotImplementedError("accelerated path: num_heads in {1,2,4}")
+        if weight_dtype not in ("fp32", "bf16"):
+            raise ValueError("weight_dtype must be 'fp32' or 'bf16'")
+        self.weight_dtype = weight_dtype
+
+        d = self.latent_dim
+        self.time_embedding = _TimestepEmbeddingParams(text_encoded_dim, d)
+        self.query_pos = _PositionEmbeddingLearned1D(d)
+        self.mem_pos = _PositionEmbeddingLearned1D(d)    # unused in trans_enc, kept for state_dict parity
+        self.encoder = _SkipStackParams(lambda: _MDLayerParams(d, ff_size, num_heads, dropout), num_layers, d)
+
+        self._wcache = None
+        self._ws = None
+        self._table_cache = {}
+
+    # ------------------------------------------------------------------ weight image
+    def _layout(self):
+        n = 5 * len(_LAYER_FIELDS) + 5
+        buf = (C.c_int64 * n)()
+        L.check(L.lib().seeme_den_layout(1024, self.ff_size, buf, n), "seeme_den_layout")
+        vals = list(buf)
+        layers = [dict(zip(_LAYER_FIELDS, vals[i * 30:(i + 1) * 30])) for i in range(5)]
+        pe0, fnw, fnb, wg_total, vp_total = vals[150:155]
+        return layers, pe0, fnw, fnb, wg_total, vp_total
+
+    def _weights(self):
+        fpnt = (_param_fingerprint(self), self.weight_dtype)
+        if self._wcache is not None and self._wcache[0] == fpnt:
+            return self._wcache[1]
+        for p in self.parameters():
+            L.require_cuda(p, "MldDenoiser parameter")
+        dev = self.query_pos.pe.device
+        layers, pe0, fnw, fnb, wg_total, vp_total = self._layout()
+        bf16 = self.weight_dtype == "bf16"
+        KV = 8 if bf16 else 4
+        wg = torch.zeros(wg_total, dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+        vp = torch.zeros(vp_total, dtype=torch.float32, device=dev)
+
+        def put_w(off, W):   # PyTorch [N,K] -> GEMV layout [K/KV][N][KV]
+            N, K = W.shape
+            g = W.detach().reshape(N, K // KV, KV).permute(1, 0, 2).reshape(-1)
+            wg[off:off + g.numel()] = g.to(wg.dtype)
+
+        def put_v(off, v):
+            vp[off:off + v.numel()] = v.detach().reshape(-1)
+
+        blocks = self.encoder.blocks()
+        with torch.no_grad():
+            put_v(pe0, self.query_pos.pe[0, 0])
+            put_v(fnw, self.encoder.norm.weight)
+            put_v(fnb, self.encoder.norm.bias)
+            for l, (blk, o) in enumerate(zip(blocks, layers)):
+                sa, ca, ffn = blk.sa_block, blk.ca_block, blk.ffn
+                if l >= 3:
+                    put_w(o["skip"], self.encoder.linear_blocks[l - 3].weight)
+                    put_v(o["skip_b"], self.encoder.linear_blocks[l - 3].bias)
+                put_w(o["inp"], sa.self_attn.in_proj_weight); put_v(o["in_b"], sa.self_attn.in_proj_bias)
+                put_w(o["outp"], sa.self_attn.out_proj.weight); put_v(o["out_b"], sa.self_attn.out_proj.bias)
+                put_w(o["l1"], sa.linear1.weight); put_v(o["l1b"], sa.linear1.bias)
+                put_w(o["l2"], sa.linear2.weight); put_v(o["l2b"], sa.linear2.bias)
+                put_v(o["n1w"], sa.norm1.weight); put_v(o["n1b"], sa.norm1.bias)
+                put_v(o["n2w"], sa.norm2.weight); put_v(o["n2b"], sa.norm2.bias)
+                put_v(o["cnw"], ca.norm.weight); put_v(o["cnb"], ca.norm.bias)
+                put_w(o["caq"], ca.query.weight); put_v(o["caq_b"], ca.query.bias)
+                put_v(o["csnw"], ca.proj_out.norm.weight); put_v(o["csnb"], ca.proj_out.norm.bias)
+                put_w(o["cao"], ca.proj_out.out_layers[2].weight); put_v(o["cao_b"], ca.proj_out.out_layers[2].bias)
+                put_w(o["f1"], ffn.linear1.weight); put_v(o["f1b"], ffn.linear1.bias)
+                put_w(o["f2"], ffn.linear2.weight); put_v(o["f2b"], ffn.linear2.bias)
+                put_v(o["fsnw"], ffn.proj_out.norm.weight); put_v(o["fsnb"], ffn.proj_out.norm.bias)
+                put_w(o["fo"], ffn.proj_out.out_layers[2].weight); put_v(o["fo_b"], ffn.proj_out.out_layers[2].bias)
+            kv_w = torch.cat([b.sa_block.self_attn.in_proj_weight[256:] for b in blocks]).contiguous()
+            kv_b = torch.cat([b.sa_block.self_attn.in_proj_bias[256:] for b in blocks]).contiguous()
+            st_w = torch.cat([torch.cat([b.ca_block.proj_out.emb_layers[1].weight, b.ffn.proj_out.emb_layers[1].weight])
+                              for b in blocks]).contiguous()
+            st_b = torch.cat([torch.cat([b.ca_block.proj_out.emb_layers[1].bias, b.ffn.proj_out.emb_layers[1].bias])
+                              for b in blocks]).contiguous()
+            ca_w = [torch.cat([b.ca_block.key.weight, b.ca_block.value.weight]).contiguous() for b in blocks]
+            ca_b = [torch.cat([b.ca_block.key.bias, b.ca_block.value.bias]).contiguous() for b in blocks]
+        w = L.DenoiserWeights()
+        w.wg, w.wdtype, w.vp = wg.data_ptr(), 1 if bf16 else 0, vp.data_ptr()
+        w.nhead, w.ff_sa, w.ff = self.num_heads, 1024, self.ff_size
+        w.kv_cat_w, w.kv_cat_b, w.style_cat_w, w.style_cat_b = kv_w.data_ptr(), kv_b.data_ptr(), st_w.data_ptr(), st_b.data_ptr()
+        te = self.time_embedding
+        w.time_w1, w.time_b1 = L.ptr(te.linear_1.weight), L.ptr(te.linear_1.bias)
+        w.time_w2, w.time_b2 = L.ptr(te.linear_2.weight), L.ptr(te.linear_2.bias)
+        for l, b in enumerate(blocks):
+            w.ca_kv_w[l], w.ca_kv_b[l] = ca_w[l].data_ptr(), ca_b[l].data_ptr()
+            w.ca_tn_w[l], w.ca_tn_b[l] = L.ptr(b.ca_block.text_norm.weight), L.ptr(b.ca_block.text_norm.bias)
+        self._wcache = (fpnt, w, (wg, vp, kv_w, kv_b, st_w, st_b, ca_w, ca_b))
+        self._table_cache = {}
+        return w
+
+    def _workspace(self, rows: int, device):
+        need = L.lib().seeme_denoiser_workspace_bytes(rows, 0, 0)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ------------------------------------------------------------------ tables
+    def time_tables(self, tfeat: torch.Tensor) -> torch.Tensor:
+        """[rows,256] sinusoidal features -> [rows, 7680] (K|V of the time token, AdaLN scale|shift)."""
+        L.require_cuda(tfeat, "tfeat")
+        tfeat = tfeat.contiguous()
+        rows = tfeat.shape[0]
+        ttab = torch.empty(rows, L.TROW, device=tfeat.device, dtype=torch.float32)
+        ws = self._workspace(rows, tfeat.device)
+        w = self._weights()
+        L.check(L.lib().seeme_denoiser_time_tables(C.byref(w), tfeat.data_ptr(), rows, ttab.data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), L.current_stream()),
+                "seeme_denoiser_time_tables")
+        return ttab
+
+    def cond_tables(self, cond_bf: torch.Tensor) -> torch.Tensor:
+        """[Bc,N,256] batch-first condition tokens -> [Bc,N,5120] step-invariant K/V tables."""
+        L.require_cuda(cond_bf, "condition")
+        cond_bf = cond_bf.contiguous()
+        Bc, N, _ = cond_bf.shape
+        ctab = torch.empty(Bc, N, L.CROW, device=cond_bf.device, dtype=torch.float32)
+        w = self._weights()
+        L.check(L.lib().seeme_denoiser_cond_tables(C.byref(w), cond_bf.data_ptr(), Bc, N, ctab.data_ptr(), 0, 0,
+                                                    L.current_stream()), "seeme_denoiser_cond_tables")
+        return ctab
+
+    def _launch(self, latents2d, ctab, ttab, trow, per_sample, steps, sched, coef, noise, cfg, guidance):
+        B, N = latents2d.shape[0], ctab.shape[1]
+        out = torch.empty(B, self.latent_dim, device=latents2d.device, dtype=torch.float32)
+        a = L.SampleArgs()
+        a.B, a.N, a.steps, a.sched, a.cfg, a.guidance_scale = B, N, steps, sched, int(cfg), float(guidance)
+        a.latents, a.ctab, a.ttab, a.trow, a.trow_per_sample = latents2d.data_ptr(), ctab.data_ptr(), ttab.data_ptr(), trow.data_ptr(), int(per_sample)
+        a.coef, a.noise, a.out = L.ptr(coef), L.ptr(noise), out.data_ptr()
+        w = self._weights()
+        L.check(L.lib().seeme_denoiser_sample(C.byref(w), C.byref(a), L.current_stream()), "seeme_denoiser_sample")
+        return out
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, sample, timestep, encoder_hidden_states, lengths=None, **kwargs):
+        """sample [B,1,256]; timestep 0-d or [B]; encoder_hidden_states [N,B,256] -> ([B,1,256],)."""
+        L.require_cuda(sample, "sample")
+        L.require_cuda(encoder_hidden_states, "encoder_hidden_states")
+        B = sample.shape[0]
+        if sample.shape[1] != 1:
+            raise NotImplementedError("accelerated path: one latent token (latent_dim [1,256])")
+        t = torch.as_tensor(timestep)
+        per_sample = t.dim() > 0 and t.numel() > 1
+        t1 = t.reshape(-1) if per_sample else t.reshape(1)            # mld_denoiser.py:167 (expand)
+        tfeat = timestep_features(t1.to(sample.device), self.text_encoded_dim, self.flip_sin_to_cos, self.freq_shift)
+        ttab = self.time_tables(tfeat.to(torch.float32))
+        trow = (torch.arange(B, dtype=torch.int32, device=sample.device) if per_sample
+                else torch.zeros(max(B, 1), dtype=torch.int32, device=sample.device))
+        ctab = self.cond_tables(encoder_hidden_states.permute(1, 0, 2))
+        out = self._launch(sample.reshape(B, -1).contiguous(), ctab, ttab, trow, True, 1, L.SCHED_NONE,
+                           None, None, False, 1.0)
+        return (out.reshape(B, 1, self.latent_dim),)
+
+    # ------------------------------------------------------------------ fused loop
+    def sample_loop(self, latents: torch.Tensor, cond_bf: torch.Tensor, scheduler, eta: float = 0.0,
+                    guidance_scale: float = 1.0, step_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """MLD._diffusion_reverse (mld.py:467-497) fused.  latents [B,1,256] (already scaled by
+        init_noise_sigma); cond_bf batch-first [B or 2B,N,256] (uncond first when guidance_scale > 1);
+        scheduler: seeme_amd.schedulers.* after set_timesteps().  Returns [1,B,256]."""
+        L.require_cuda(latents, "latents")
+        B = latents.shape[0]
+        cfg = guidance_scale > 1.0
+        if cond_bf.shape[0] != (2 * B if cfg else B):
+            raise ValueError("condition batch must be B (or 2B with classifier-free guidance)")
+        dev = latents.device
+        key = (tuple(scheduler.timesteps.tolist()), float(eta), type(scheduler).__name__)
+        cached = self._table_cache.get(key)
+        self._weights()
+        if cached is None:
+            tfeat = timestep_features(scheduler.timesteps.cpu(), self.text_encoded_dim, self.flip_sin_to_cos,
+                                      self.freq_shift).to(dev)
+            coef = scheduler.coef_table(eta).to(dev)
+            trow = torch.arange(len(scheduler.timesteps), dtype=torch.int32, device=dev)
+            cached = (tfeat, coef, trow)
+            self._table_cache = {key: cached}
+        tfeat, coef, trow = cached
+        ttab = self.time_tables(tfeat)                     # batch-invariant: once per call
+        ctab = self.cond_tables(cond_bf)
+        steps = len(trow)
+        noise = None
+        if scheduler.needs_noise(eta):
+            if step_noise is None:
+                step_noise = torch.randn(steps, B, self.latent_dim, device=dev, dtype=torch.float32)
+            noise = step_noise.reshape(steps, B, self.latent_dim).contiguous()
+        sched = L.SCHED_DDIM if type(scheduler).__name__.startswith("DDIM") else L.SCHED_DDPM
+        out = self._launch(latents.reshape(B, -1).contiguous(), ctab, ttab, trow, False, steps, sched, coef, noise,
+                           cfg, guidance_scale)
+        return out.reshape(1, B, self.latent_dim)

@@ -1,0 +1,122 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, host logic
+(schedulers, state-dict surface, packing layout) matches the oracle / the reference's key lists."""
+import ctypes as C
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, rel_err
+from oracle import mld_oracle as O
+from seeme_amd import shapes
+
+
+def _abl():
+    return types.SimpleNamespace(MLP_DIST=False, PE_TYPE="mld", SKIP_CONNECT=True, VAE_TYPE="actor",
+                                 DIFF_PE_TYPE="mld", MD_TRANS=True)
+
+
+def test_library_exports_every_declared_symbol():
+    from seeme_amd import _lib
+    lib = _lib.lib()   # raises if the .so is missing or a symbol is absent
+    hdr = open(os.path.join(REPO, "include", "seeme_hip.h")).read()
+    declared = set(re.findall(r"\b(seeme_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "header parse failed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/seeme_hip.h but not exported"
+    assert declared <= set(_lib.exported_symbols()) | {"seeme_make_den_layout"}
+    assert lib.seeme_version() >= 100
+
+
+def test_den_layout_is_consistent():
+    from seeme_amd import _lib
+    n = 155
+    buf = (C.c_int64 * n)()
+    assert _lib.lib().seeme_den_layout(1024, 128, buf, n) == 0
+    v = list(buf)
+    wg_total, vp_total = v[153], v[154]
+    # matrices of one step: 5 layers + 2 skip linears
+    per_layer = 3 * 65536 + 65536 + 2 * 1024 * 256 + 2 * 65536 + 2 * 128 * 256 + 65536
+    assert wg_total == 5 * per_layer + 2 * 2 * 65536
+    assert vp_total > 0 and v[0] == -1 and v[3 * 30] >= 0   # skip offset only for layers 3,4
+
+
+def test_no_cpu_fallback():
+    from seeme_amd.mld_vae import MldVae
+    from seeme_amd._lib import SeemeError
+    vae = MldVae(_abl(), nfeats=75, arch="encoder_decoder")
+    with pytest.raises(SeemeError):
+        vae.encode(torch.zeros(1, 8, 75), None, [8])
+
+
+def test_state_dict_surface_matches_reference_key_lists():
+    from seeme_amd.mld_vae import MldVae
+    from seeme_amd.mld_denoiser import MldDenoiser
+    vae = MldVae(_abl(), nfeats=75, arch="encoder_decoder")
+    sd = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+    assert sd == shapes.vae_shapes(75)
+    assert sum(int(np.prod(s)) for s in sd.values()) == 5441099
+    den = MldDenoiser(_abl(), condition=["text", "interactee"], ff_size=128, num_layers=5, num_heads=1)
+    sd = {k: tuple(v.shape) for k, v in den.state_dict().items()}
+    assert sd == shapes.denoiser_shapes()
+    assert sum(int(np.prod(s)) for s in sd.values()) == 7900032
+
+
+def test_unsupported_configs_raise_like_the_reference():
+    from seeme_amd.mld_vae import MldVae
+    from seeme_amd.mld_denoiser import MldDenoiser
+    a = _abl()
+    a.PE_TYPE = "bogus"
+    with pytest.raises(ValueError):
+        MldVae(a, nfeats=75, arch="encoder_decoder")
+    with pytest.raises(ValueError):
+        MldVae(_abl(), nfeats=75, arch="bogus")
+    with pytest.raises(ValueError):
+        MldDenoiser(_abl(), condition=["text"], arch="bogus", num_layers=5, num_heads=1)
+    with pytest.raises(TypeError):
+        MldDenoiser(_abl(), condition=["scene"], num_layers=5, num_heads=1)
+
+
+def test_schedulers_match_oracle():
+    from seeme_amd.schedulers import DDIMScheduler, DDPMScheduler
+    kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False)
+    ddim = DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **kw)
+    ddim.set_timesteps(50)
+    acp = O.alphas_cumprod(O.make_betas())
+    assert np.allclose(ddim.alphas_cumprod.numpy(), acp, rtol=1e-6)
+    assert ddim.timesteps.tolist() == O.ddim_timesteps(50).tolist()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((3, 1, 256)).astype(np.float32)
+    e = rng.standard_normal((3, 1, 256)).astype(np.float32)
+    n = rng.standard_normal((3, 1, 256)).astype(np.float32)
+    for t in (981, 501, 1):
+        for eta in (0.0, 0.5):
+            got = ddim.step(torch.from_numpy(e), t, torch.from_numpy(x), eta=eta, variance_noise=torch.from_numpy(n)).prev_sample
+            assert rel_err(got.numpy(), O.ddim_step(acp, e, t, x, 50, eta, n)) < 1e-5
+    # the coefficient table reproduces step() (this is what the fused kernel consumes)
+    c = ddim.coef_table(0.5).numpy()
+    for i, t in enumerate(ddim.timesteps.tolist()[:3]):
+        x0 = (x - c[i, 1] * e) / c[i, 0]
+        prev = c[i, 2] * x0 + c[i, 3] * e + c[i, 5] * x + c[i, 4] * n
+        assert rel_err(prev, O.ddim_step(acp, e, t, x, 50, 0.5, n)) < 1e-5
+    ddpm = DDPMScheduler(variance_type="fixed_small", **kw)
+    tt = np.array([999, 0, 37])
+    got = ddpm.add_noise(torch.from_numpy(x), torch.from_numpy(n), torch.from_numpy(tt))
+    assert rel_err(got.numpy(), O.ddpm_add_noise(acp, x, n, tt)) < 1e-6
+    ddpm.set_timesteps(1000)
+    for t in (999, 500, 0):
+        got = ddpm.step(torch.from_numpy(e), t, torch.from_numpy(x), variance_noise=torch.from_numpy(n)).prev_sample
+        assert rel_err(got.numpy(), O.ddpm_step(acp, e, t, x, n)) < 1e-5
+    c = ddpm.coef_table().numpy()
+    i = 0
+    x0 = (x - c[i, 1] * e) / c[i, 0]
+    assert rel_err(c[i, 2] * x0 + c[i, 5] * x + c[i, 4] * n, O.ddpm_step(acp, e, 999, x, n)) < 1e-5
+
+
+def test_timestep_features_match_oracle():
+    from seeme_amd.mld_denoiser import timestep_features
+    t = torch.tensor([0, 1, 21, 501, 981, 999])
+    assert rel_err(timestep_features(t).numpy(), O.timestep_features(t.numpy())) < 1e-4
