@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- sampled sequences / second on the motion-latent-diffusion hot path.
+
+One "step" = one pass of the path over one batch of synthetic input, per GPU:
+    interactee motion [B,196,132] --MldVae.encode--> condition token
+    latents [B,1,256] --50-step DDIM loop through MldDenoiser (one persistent kernel)--> z
+    z --MldVae.decode--> motion [B,196,132]
+(BASELINE.json configs[1]: config_mld_egobody.yaml interactee-only denoiser, 50 DDIM steps, B=32.)
+All inputs are resident in HBM before the timed region.  Weights are random-init by the seeded
+recipe (no checkpoint exists offline); data is synthetic N(0,1) of the named shape.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` (dominant kernel,
+timed with events on its own stream) and `cpu_baseline` (the numpy oracle on the host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+T_FRAMES, NFEATS, DDIM_STEPS = 196, 132, 50
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def ablation():
+    return types.SimpleNamespace(MLP_DIST=False, PE_TYPE="mld", SKIP_CONNECT=True, VAE_TYPE="actor",
+                                 DIFF_PE_TYPE="mld", MD_TRANS=True)
+
+
+def build_models(dev, weight_dtype):
+    from seeme_amd.mld_denoiser import MldDenoiser
+    from seeme_amd.mld_vae import MldVae
+    from seeme_amd.schedulers import DDIMScheduler
+    from seeme_amd.weights_recipe import load_recipe_
+    vae = load_recipe_(MldVae(ablation(), nfeats=NFEATS, latent_dim=[1, 256], arch="encoder_decoder")).to(dev).eval()
+    den = load_recipe_(MldDenoiser(ablation(), nfeats=NFEATS, condition=["text", "interactee"], latent_dim=[1, 256],
+                                   ff_size=128, num_layers=5, num_heads=1, weight_dtype=weight_dtype)).to(dev).eval()
+    sch = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                        clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    sch.set_timesteps(DDIM_STEPS)
+    return vae, den, sch
+
+
+def one_pass(vae, den, sch, motion, latents, lengths, ev=None):
+    dist = vae.encode_dist(motion, lengths)                 # [2,B,256]; mu is the condition (ego_eval, mld.py:1271-1295)
+    cond = dist[0].unsqueeze(1)                             # [B,1,256] batch-first, N = 1 token
+    z = den.sample_loop(latents, cond, sch, events=ev)   # event pair brackets only the persistent kernel
+    return vae.decode(z, lengths)
+
+
+def den_algorithmic_bytes(den, B, N, steps):
+    """Bytes one launch of the sampling kernel must touch: per step the packed weight image (read once
+    per step for the whole batch) + the time-table row; per sample the condition tables and the latent."""
+    w = den._weights()
+    keep = den._wcache[2]
+    wg, vp = keep[0], keep[1]
+    per_step = wg.numel() * wg.element_size() + vp.numel() * 4 + 7680 * 4
+    per_sample = N * 5120 * 4 + 2 * 256 * 4
+    return steps * per_step + B * per_sample
+
+
+def cpu_baseline(B, budget_s=12.0):
+    """The numpy oracle (a port of the reference CPU path, pinned to it by tests/golden) on this host."""
+    from oracle import mld_oracle as O
+    from seeme_amd import shapes
+    from seeme_amd.weights_recipe import recipe_state_dict
+    Pv, Pd = recipe_state_dict(shapes.vae_shapes(NFEATS)), recipe_state_dict(shapes.denoiser_shapes())
+    rng = np.random.Generator(np.random.PCG64(1234))
+    Bc = min(B, 8)
+    motion = rng.standard_normal((Bc, T_FRAMES, NFEATS)).astype(np.float32)
+    lat = rng.standard_normal((Bc, 1, 256)).astype(np.float32)
+    lengths = [T_FRAMES] * Bc
+    n, t0 = 0, time.perf_counter()
+    while True:
+        mu, _ = O.vae_encode(Pv, motion, lengths)
+        z = O.diffusion_reverse(Pd, np.transpose(mu, (1, 0, 2)), lat, DDIM_STEPS)
+        O.vae_decode(Pv, z, lengths)
+        n += Bc
+        dt = time.perf_counter() - t0
+        if dt > budget_s:
+            break
+    return {"value": round(n / dt, 3), "unit": "seqs/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} sequences (passes of B={Bc}, T=196, 50 DDIM steps) in {dt:.1f}s, numpy/OpenBLAS fp32 oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="sequences per GPU per pass (BASELINE configs[1]: 32)")
+    ap.add_argument("--weights", default="bf16", choices=["fp32", "bf16"], help="denoiser weight image dtype")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.batch
+    vae, den, sch = build_models(dev, args.weights)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    motion = torch.randn(B, T_FRAMES, NFEATS, generator=g).to(dev)
+    latents = torch.randn(B, 1, 256, generator=g).to(dev)
+    lengths = [T_FRAMES] * B
+
+    for _ in range(args.warmup):
+        one_pass(vae, den, sch, motion, latents, lengths)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_pass(vae, den, sch, motion, latents, lengths, evs[i])
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all()
+
+    # dominant kernel: the persistent DDIM kernel
+    loop_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    alg_bytes = den_algorithmic_bytes(den, B, 1, DDIM_STEPS)
+    achieved = alg_bytes / (loop_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        res = {
+            "metric": "sampled seqs/sec (T=196, 50 DDIM steps)",
+            "value": round(world * B * args.steps / dt, 2),
+            "unit": "seqs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if args.weights == "fp32" else "f32 (bf16 denoiser weights)",
+            "data": "synthetic",
+            "config": {"workload": f"config_mld_egobody interactee-only: VAE encode -> 50-step DDIM -> VAE decode, "
+                                   f"B={B}/GPU, T=196, nfeats=132, random-init recipe weights",
+                       "batch_per_gpu": B, "seq_len": T_FRAMES, "ddim_steps": DDIM_STEPS,
+                       "parallelism": f"dp{world} (independent shards, no collective on the data path)"},
+            "roofline": {"bound": "hbm", "kernel": "k_den_sample (persistent DDIM loop)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "ms_per_launch": round(loop_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(B)
+        print(json.dumps(res), flush=True)
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

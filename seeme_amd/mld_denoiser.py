@@ -294,7 +294,8 @@ class MldDenoiser(nn.Module):
 
     # ------------------------------------------------------------------ fused loop
     def sample_loop(self, latents: torch.Tensor, cond_bf: torch.Tensor, scheduler, eta: float = 0.0,
-                    guidance_scale: float = 1.0, step_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    guidance_scale: float = 1.0, step_noise: Optional[torch.Tensor] = None,
+                    events=None) -> torch.Tensor:
         """MLD._diffusion_reverse (mld.py:467-497) fused.  latents [B,1,256] (already scaled by
         init_noise_sigma); cond_bf batch-first [B or 2B,N,256] (uncond first when guidance_scale > 1);
         scheduler: seeme_amd.schedulers.* after set_timesteps().  Returns [1,B,256]."""
@@ -324,6 +325,10 @@ class MldDenoiser(nn.Module):
                 step_noise = torch.randn(steps, B, self.latent_dim, device=dev, dtype=torch.float32)
             noise = step_noise.reshape(steps, B, self.latent_dim).contiguous()
         sched = L.SCHED_DDIM if type(scheduler).__name__.startswith("DDIM") else L.SCHED_DDPM
-        out = self._launch(latents.reshape(B, -1).contiguous(), ctab, ttab, trow, False, steps, sched, coef, noise,
-                           cfg, guidance_scale)
+        lat2 = latents.reshape(B, -1).contiguous()
+        if events is not None:     # (start, end) torch.cuda.Event pair bracketing only the persistent kernel
+            events[0].record()
+        out = self._launch(lat2, ctab, ttab, trow, False, steps, sched, coef, noise, cfg, guidance_scale)
+        if events is not None:
+            events[1].record()
         return out.reshape(1, B, self.latent_dim)
