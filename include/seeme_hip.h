@@ -112,11 +112,12 @@ int seeme_vae_decode(const SeemeVaeWeights* w, const float* z, const int32_t* le
  *   wg : GEMV-layout matrices, element type fp32 or bf16 (wdtype 0 / 1); a [N,K] PyTorch matrix is
  *        stored as [K/KV][N][KV] with KV = 4 (fp32) or 8 (bf16) so that a wave reads 1 KiB contiguous;
  *   vp : fp32 vectors (biases, LayerNorm params, pe row 0);
- * in the order documented in seeme_amd/csrc/den_layout.h (mirrored by seeme_amd/_pack.py).
+ * in the order documented in seeme_amd/csrc/den_layout.h; seeme_den_layout() exports the offsets.
  */
 typedef struct {
     const void*  wg;   int wdtype;       /* 0 = fp32, 1 = bf16 */
     const float* vp;
+    const int64_t* layout;               /* device copy of the seeme_den_layout() table (155 int64) */
     int nhead;                           /* 1, 2 or 4 */
     int ff_sa;                           /* 1024 (hard-coded mdiff_transformer.py:279) */
     int ff;                              /* 128 */
@@ -164,6 +165,9 @@ typedef struct {
 } SeemeSampleArgs;
 
 int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeSampleArgs* a, void* stream);
+
+/* Offsets of the packed weight image (30 per layer x 5, then pe0, fnw, fnb, wg_total, vp_total). */
+int seeme_den_layout(int ff_sa, int ff, int64_t* out, int cap);
 
 /* ------------------------------------------------------------------ SMPL linear blend skinning
  * smplx.SMPL.forward (call sites mld/models/modeltype/mld.py:764-770 ...). */

@@ -51,7 +51,7 @@ class VaeWeights(C.Structure):
 
 
 class DenoiserWeights(C.Structure):
-    _fields_ = [("wg", fp), ("wdtype", C.c_int), ("vp", fp), ("nhead", C.c_int), ("ff_sa", C.c_int),
+    _fields_ = [("wg", fp), ("wdtype", C.c_int), ("vp", fp), ("layout", fp), ("nhead", C.c_int), ("ff_sa", C.c_int),
                 ("ff", C.c_int), ("kv_cat_w", fp), ("kv_cat_b", fp), ("style_cat_w", fp), ("style_cat_b", fp),
                 ("time_w1", fp), ("time_b1", fp), ("time_w2", fp), ("time_b2", fp),
                 ("ca_kv_w", fp * NLAYERS), ("ca_kv_b", fp * NLAYERS),

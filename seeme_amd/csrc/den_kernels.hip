@@ -15,120 +15,163 @@
 #include "common.hpp"
 #include "api_util.hpp"
 #include "den_layout.h"
+#include <utility>
 
 #define DEN_THREADS 512
 #define DEN_MAXTOK 6   // 1 latent + N<=4 condition tokens + 1 time token
+#ifndef DEN_CHMAX
+#define DEN_CHMAX 8    // 16-B vectors per lane per chunk (two chunks in flight: 2 x 8 x 4 = 64 VGPRs)
+#endif
 
 // ------------------------------------------------------------------ weight element types
-struct WF32 { typedef float T; static constexpr int KV = 4; };
-struct WBF16 { typedef uint16_t T; static constexpr int KV = 8; };
+struct WF32 { typedef float T; static constexpr int KV = 4; };      // 16-B vector = 4 weights
+struct WBF16 { typedef uint16_t T; static constexpr int KV = 8; };  // 16-B vector = 8 weights
 
-// partial dot products of output n over k-groups [q0, q0+nq) for MS samples
-template <int MS>
-__device__ __forceinline__ void gemv_part(const float* __restrict__ Wp, int N, int n, int q0, int nq,
-                                          const float* __restrict__ x, int ldx, float (&sum)[MS]) {
-    const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)q0 * N + n;
-    float acc[MS][4];
-#pragma unroll
-    for (int s = 0; s < MS; ++s) acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0.f;
-#pragma unroll 8
-    for (int q = 0; q < nq; ++q) {
-        const float4 w = wp[(size_t)q * N];
-#pragma unroll
-        for (int s = 0; s < MS; ++s) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + s * ldx + 4 * (q0 + q));
-            acc[s][0] = fmaf(w.x, xv.x, acc[s][0]);
-            acc[s][1] = fmaf(w.y, xv.y, acc[s][1]);
-            acc[s][2] = fmaf(w.z, xv.z, acc[s][2]);
-            acc[s][3] = fmaf(w.w, xv.w, acc[s][3]);
-        }
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// One chunk of this thread's weight stream: up to DEN_CHMAX x 16 B per lane.
+struct WBuf { u32x4 r[DEN_CHMAX]; };
+// Where the NEXT GEMV's first chunk of this thread lives (weights do not depend on activations, so
+// it is requested before the current GEMV's epilogue and lands while the reductions/barriers run).
+// Addresses are buffer-load style: per-thread byte offset (VGPR) + wave-uniform byte offset (SGPR),
+// so no 64-bit per-chunk pointers are kept in vector registers.
+struct NextPre { unsigned voff; unsigned soff; int stride; int ch; };
+
+// GEMV work split over the 512 threads.  A PyTorch [N,K] matrix is stored as [K/KV][N] 16-B vectors;
+// an "item" = (k-slice ks, output n); thread tid owns items tid, tid+512, ...
+template <typename WT, int K, int N>
+struct GemvShape {
+    static constexpr int KS = (N >= 512) ? ((N % 512 == 0) ? 1 : 2) : (512 / N);   // k-slices
+    static constexpr int NQ = K / WT::KV / KS;                                      // vectors per item
+    static constexpr int CH = (NQ / 2 < DEN_CHMAX) ? (NQ / 2) : DEN_CHMAX;                       // vectors per chunk
+    static constexpr int CPI = NQ / CH;                                             // chunks per item
+    static constexpr int IT = N * KS / DEN_THREADS;                                 // items per thread
+    static constexpr int TOT = IT * CPI;                                            // chunks per thread
+    static_assert(N * KS % DEN_THREADS == 0 && NQ % CH == 0 && TOT % 2 == 0 && CH >= 1, "unsupported GEMV shape");
+    // per-thread byte offset of item `it` (vector (ks*NQ)*N + n)
+    __device__ static __forceinline__ unsigned item_voff(int tid, int it) {
+        const int idx = tid + it * DEN_THREADS;
+        const int ks = idx / N, n = idx - ks * N;
+        return (unsigned)(ks * NQ * N + n) * 16u;
     }
+    // wave-uniform byte offset of chunk c of an item, relative to the matrix start
+    static constexpr unsigned chunk_soff(int c) { return (unsigned)(c * CH) * N * 16u; }
+    __device__ static __forceinline__ NextPre pre(int tid, long long w_elem_off) {
+        return NextPre{item_voff(tid, 0), (unsigned)(w_elem_off * (long long)sizeof(typename WT::T)), N * 16, CH};
+    }
+};
+
+__device__ __forceinline__ void issue_rt(WBuf& b, __amdgpu_buffer_rsrc_t rsrc, const NextPre np) {
 #pragma unroll
-    for (int s = 0; s < MS; ++s) sum[s] = (acc[s][0] + acc[s][1]) + (acc[s][2] + acc[s][3]);
+    for (int i = 0; i < DEN_CHMAX; ++i)
+        if (i < np.ch) b.r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, np.voff, np.soff + (unsigned)(i * np.stride), 0);
+}
+template <int CH, int STRIDE>
+__device__ __forceinline__ void issue_ct(WBuf& b, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) b.r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + (unsigned)(i * STRIDE), 0);
 }
 
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
-template <int MS>
-__device__ __forceinline__ void gemv_part(const uint16_t* __restrict__ Wp, int N, int n, int q0, int nq,
-                                          const float* __restrict__ x, int ldx, float (&sum)[MS]) {
-    const uint4* wp = reinterpret_cast<const uint4*>(Wp) + (size_t)q0 * N + n;
-    float acc[MS][4];
+// acc[s] += W-chunk . x[s][k0 ...]   (x in LDS, broadcast reads; packed fp32 FMAs)
+template <typename WT, int CH, int MS>
+__device__ __forceinline__ void consume(const WBuf& b, const float* __restrict__ x, int ldx, int k0, f2 (&acc)[MS][2]) {
 #pragma unroll
-    for (int s = 0; s < MS; ++s) acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0.f;
-#pragma unroll 8
-    for (int q = 0; q < nq; ++q) {
-        const uint4 w = wp[(size_t)q * N];
+    for (int i = 0; i < CH; ++i) {
+        const u32x4 u = b.r[i];
 #pragma unroll
         for (int s = 0; s < MS; ++s) {
-            const float* xp = x + s * ldx + 8 * (q0 + q);
+            const float* xp = x + s * ldx + k0 + WT::KV * i;
             const float4 x0 = *reinterpret_cast<const float4*>(xp);
-            const float4 x1 = *reinterpret_cast<const float4*>(xp + 4);
-            acc[s][0] = fmaf(bf_lo(w.x), x0.x, acc[s][0]);
-            acc[s][1] = fmaf(bf_hi(w.x), x0.y, acc[s][1]);
-            acc[s][2] = fmaf(bf_lo(w.y), x0.z, acc[s][2]);
-            acc[s][3] = fmaf(bf_hi(w.y), x0.w, acc[s][3]);
-            acc[s][0] = fmaf(bf_lo(w.z), x1.x, acc[s][0]);
-            acc[s][1] = fmaf(bf_hi(w.z), x1.y, acc[s][1]);
-            acc[s][2] = fmaf(bf_lo(w.w), x1.z, acc[s][2]);
-            acc[s][3] = fmaf(bf_hi(w.w), x1.w, acc[s][3]);
+            if constexpr (WT::KV == 4) {
+                acc[s][0] += f2{__uint_as_float(u.x), __uint_as_float(u.y)} * f2{x0.x, x0.y};
+                acc[s][1] += f2{__uint_as_float(u.z), __uint_as_float(u.w)} * f2{x0.z, x0.w};
+            } else {
+                const float4 x1 = *reinterpret_cast<const float4*>(xp + 4);
+                acc[s][0] += f2{bf_lo(u.x), bf_hi(u.x)} * f2{x0.x, x0.y};
+                acc[s][1] += f2{bf_lo(u.y), bf_hi(u.y)} * f2{x0.z, x0.w};
+                acc[s][0] += f2{bf_lo(u.z), bf_hi(u.z)} * f2{x1.x, x1.y};
+                acc[s][1] += f2{bf_lo(u.w), bf_hi(u.w)} * f2{x1.z, x1.w};
+            }
         }
     }
-#pragma unroll
-    for (int s = 0; s < MS; ++s) sum[s] = (acc[s][0] + acc[s][1]) + (acc[s][2] + acc[s][3]);
 }
 
-// y[s][n] = act(W x[s] + bias)[n] -> LDS out[s*ldo + n].  Ends with a barrier.
-template <typename WT, int MS>
-__device__ __forceinline__ void gemv_lds(const typename WT::T* __restrict__ Wp, int K, int N,
-                                         const float* __restrict__ x, int ldx, const float* __restrict__ bias,
-                                         int act, float* __restrict__ out, int ldo, float* __restrict__ part) {
-    const int tid = threadIdx.x;
-    const int nq_total = K / WT::KV;
-    if (N >= DEN_THREADS) {
-        for (int n = tid; n < N; n += DEN_THREADS) {
-            float s[MS];
-            gemv_part<MS>(Wp, N, n, 0, nq_total, x, ldx, s);
+// One pipeline step t of a GEMV: request chunk t+1 (or the next GEMV's first chunk), then consume chunk t.
+// Chunk t lives in A for even t and in B for odd t; TOT is even, so a GEMV starts and ends on A.
+template <typename WT, int K, int N, int MS, int T>
+__device__ __forceinline__ void gemv_step(int tid, __amdgpu_buffer_rsrc_t rsrc, unsigned wbase, const float* __restrict__ x, int ldx,
+                                          WBuf& A, WBuf& B, const NextPre& next, float* __restrict__ part,
+                                          f2 (&acc)[MS][2]) {
+    typedef GemvShape<WT, K, N> G;
+    constexpr int it = T / G::CPI, c = T % G::CPI;
+    const int idx = tid + it * DEN_THREADS;
+    const int ks = idx / N, n = idx - ks * N;
+    if constexpr (c == 0) {
 #pragma unroll
-            for (int ms = 0; ms < MS; ++ms) out[ms * ldo + n] = act_apply(s[ms] + bias[n], act);
-        }
-        __syncthreads();
+        for (int s = 0; s < MS; ++s) { acc[s][0] = f2{0.f, 0.f}; acc[s][1] = f2{0.f, 0.f}; }
+    }
+    WBuf& cur = (T & 1) ? B : A;
+    WBuf& nxt = (T & 1) ? A : B;
+    if constexpr (T + 1 < G::TOT) {
+        constexpr int it2 = (T + 1) / G::CPI, c2 = (T + 1) % G::CPI;
+        issue_ct<G::CH, N * 16>(nxt, rsrc, G::item_voff(tid, it2), wbase + G::chunk_soff(c2));
     } else {
-        const int KS = DEN_THREADS / N, ks = tid / N, n = tid - ks * N, nq = nq_total / KS;
-        float s[MS];
-        gemv_part<MS>(Wp, N, n, ks * nq, nq, x, ldx, s);
-#pragma unroll
-        for (int ms = 0; ms < MS; ++ms) part[(ks * MS + ms) * N + n] = s[ms];
-        __syncthreads();
-        for (int idx = tid; idx < N * MS; idx += DEN_THREADS) {
-            const int ms = idx / N, nn = idx - ms * N;
-            float v = bias[nn];
-            for (int k2 = 0; k2 < KS; ++k2) v += part[(k2 * MS + ms) * N + nn];
-            out[ms * ldo + nn] = act_apply(v, act);
-        }
-        __syncthreads();
+        issue_rt(nxt, rsrc, next);
     }
+    consume<WT, G::CH, MS>(cur, x, ldx, (ks * G::NQ + c * G::CH) * WT::KV, acc);
+    if constexpr (c == G::CPI - 1) {
+#pragma unroll
+        for (int s = 0; s < MS; ++s) part[(ks * MS + s) * N + n] = (acc[s][0].x + acc[s][0].y) + (acc[s][1].x + acc[s][1].y);
+    }
+    // keep the machine scheduler from hoisting later chunks' loads above this point: exactly one chunk
+    // (plus the one being consumed) is live, which is what the register budget is sized for
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <typename WT, int K, int N, int MS, int... Ts>
+__device__ __forceinline__ void gemv_steps(int tid, __amdgpu_buffer_rsrc_t rsrc, unsigned wbase, const float* __restrict__ x, int ldx,
+                                           WBuf& A, WBuf& B, const NextPre& next, float* __restrict__ part,
+                                           f2 (&acc)[MS][2], std::integer_sequence<int, Ts...>) {
+    (gemv_step<WT, K, N, MS, Ts>(tid, rsrc, wbase, x, ldx, A, B, next, part, acc), ...);
 }
 
-// N = 256 GEMV whose result goes straight to the owner thread (sample ms = tid>>8, dim d = tid&255).
-// One barrier inside; the caller must have a barrier between this call and the next write to `part`.
-template <typename WT, int MS>
-__device__ __forceinline__ float gemv256_owner(const typename WT::T* __restrict__ Wp, int K,
-                                               const float* __restrict__ x, int ldx, float* __restrict__ part) {
-    const int tid = threadIdx.x, ks = tid >> 8, n = tid & 255;
-    const int nq = K / WT::KV / 2;
-    float s[MS];
-    gemv_part<MS>(Wp, 256, n, ks * nq, nq, x, ldx, s);
-#pragma unroll
-    for (int ms = 0; ms < MS; ++ms) part[(ks * MS + ms) * 256 + n] = s[ms];
+// part[ks][s][n] = partial dot products of W x[s]; A holds this GEMV's first chunk on entry and the
+// NEXT GEMV's first chunk (in flight) on exit.  Ends with a barrier (partials visible).
+// w_elem_off: element offset of the matrix inside the packed image.
+template <typename WT, int K, int N, int MS>
+__device__ __forceinline__ void gemv_run(int tid, __amdgpu_buffer_rsrc_t rsrc, long long w_elem_off, const float* __restrict__ x,
+                                         int ldx, WBuf& A, const NextPre next, float* __restrict__ part) {
+    WBuf B;
+    f2 acc[MS][2];
+    const unsigned wbase = (unsigned)(w_elem_off * (long long)sizeof(typename WT::T));
+    gemv_steps<WT, K, N, MS>(tid, rsrc, wbase, x, ldx, A, B, next, part, acc,
+                             std::make_integer_sequence<int, GemvShape<WT, K, N>::TOT>{});
     __syncthreads();
-    float r = 0.f;
-    if (tid < 256 * MS) {
-        const int ms = tid >> 8;
-        r = part[ms * 256 + n] + part[(MS + ms) * 256 + n];
+}
+
+// out[s][n] = act(sum_ks part + bias).  Ends with a barrier.
+template <typename WT, int K, int N, int MS>
+__device__ __forceinline__ void combine_lds(int tid, const float* __restrict__ part, const float* __restrict__ bias, int act,
+                                            float* __restrict__ out, int ldo) {
+    constexpr int KS = GemvShape<WT, K, N>::KS;
+    for (int idx = tid; idx < N * MS; idx += DEN_THREADS) {
+        const int s = idx / N, n = idx - s * N;
+        float v = bias[n];
+#pragma unroll
+        for (int k2 = 0; k2 < KS; ++k2) v += part[(k2 * MS + s) * N + n];
+        out[s * ldo + n] = act_apply(v, act);
     }
-    return r;
+    __syncthreads();
+}
+// N = 256 (KS = 2): the owner thread (sample ms = tid>>8, dim d = tid&255) picks up its own sum.
+template <int MS>
+__device__ __forceinline__ float owner256(int tid, const float* __restrict__ part) {
+    if (tid >= 256 * MS) return 0.f;
+    const int ms = tid >> 8, n = tid & 255;
+    return part[ms * 256 + n] + part[(MS + ms) * 256 + n];
 }
 
 // ------------------------------------------------------------------ group reductions
@@ -171,65 +214,89 @@ __device__ __forceinline__ float group_ln(float v, const float* __restrict__ w, 
 }
 
 // ------------------------------------------------------------------ the persistent sampling kernel
+#define FF_SA 1024   // sa_block feed-forward, hard-coded in the reference (mdiff_transformer.py:279)
+#define FF_D 128     // ffn_dim (configs/modules/denoiser.yaml:5)
+
 struct DenKArgs {
-    const void* wg; const float* vp;
-    DenLayout lay;
-    int nhead, ff_sa, ff;
+    const void* wg; int wg_bytes; const float* vp;
+    const DenLayout* lay;      // device copy of the layout (scalar loads on demand; keeps SGPR pressure low)
+    int nhead;
     SeemeSampleArgs s;
 };
 
 template <typename WT, int MS>
 __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    typedef typename WT::T wt_t;
-    const wt_t* __restrict__ wg = reinterpret_cast<const wt_t*>(ka.wg);
+    // wave-uniform buffer descriptor of the packed weight image (raw buffer loads: VGPR offset + SGPR offset)
+    const __amdgpu_buffer_rsrc_t wg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ka.wg), 0, ka.wg_bytes, 0x00020000);
     const float* __restrict__ vp = ka.vp;
+    const DenLayout* __restrict__ lay = ka.lay;
     const SeemeSampleArgs& A = ka.s;
-    const int tid = threadIdx.x, ms = tid >> 8, d = tid & 255;
-    const bool own = tid < 256 * MS;
+    const int tid0 = threadIdx.x;
     const int b = blockIdx.x, N = A.N, NS = N + 2, H = ka.nhead;
-    const int ff_sa = ka.ff_sa, ff = ka.ff;
-    const int vmax = ff_sa > 512 ? ff_sa : 512;
 
-    float* X = smem;                       // [MS][256]
-    float* LAT = X + MS * 256;             // [256]
-    float* SK = LAT + 256;                 // [2][MS][256]
-    float* VA = SK + 2 * MS * 256;         // [MS][vmax]
-    float* VB = VA + MS * vmax;            // [MS][256]
+    float* X = smem;                       // [MS][256]   current value of token 0
+    float* LAT = X + MS * 256;             // [256]       latent carried across steps
+    float* SK = LAT + 256;                 // [2][MS][256] skip stack
+    float* VA = SK + 2 * MS * 256;         // [MS][1024]  GEMV inputs / hidden activations
+    float* VB = VA + MS * FF_SA;           // [MS][256]
     float* QKV = VB + MS * 256;            // [MS][768]
-    float* PART = QKV + MS * 768;          // [4*MS*256]  (KS*MS*N <= 512*MS... sized for KS=4,N=128 / KS=2,N=256)
-    float* RED = PART + 4 * MS * 256;      // [2][8][8]
+    float* PART = QKV + MS * 768;          // [KS][MS][N] partial sums, max 2*MS*768
+    float* RED = PART + 2 * MS * 768;      // [2][8][8]
     int cnt = 0;
 
-    // condition tables of this workgroup's sample(s): CFG -> ms 0 = uncond (first half), ms 1 = cond
-    const int bc = (MS == 2) ? (ms == 0 ? b : A.B + b) : b;
-    const float* __restrict__ ct = A.ctab + (size_t)(own ? bc : b) * N * SEEME_CROW;
     const float sa_scale = 1.f / sqrtf((float)(256 / H));
 
-    if (tid < 256) LAT[tid] = A.latents[(size_t)b * 256 + tid];
+    typedef GemvShape<WT, 512, 256> G_SKIP;
+    typedef GemvShape<WT, 256, 768> G_INP;
+    typedef GemvShape<WT, 256, 256> G_SQ;
+    typedef GemvShape<WT, 256, FF_SA> G_L1;
+    typedef GemvShape<WT, FF_SA, 256> G_L2;
+    typedef GemvShape<WT, 256, FF_D> G_F1;
+    typedef GemvShape<WT, FF_D, 256> G_F2;
+
+    if (tid0 < 256) LAT[tid0] = A.latents[(size_t)b * 256 + tid0];
+    WBuf Abuf;                             // the weight chunk in flight across GEMV boundaries
+    issue_rt(Abuf, wg, G_INP::pre(tid0, lay->L[0].inp));
     __syncthreads();
 
+#pragma unroll 1
     for (int step = 0; step < A.steps; ++step) {
         const int row = A.trow_per_sample ? A.trow[b] : A.trow[step];
         const float* __restrict__ tt = A.ttab + (size_t)row * SEEME_TROW;
 
         float xr = 0.f;  // owner's current value of token 0
-        if (own) { xr = LAT[d] + vp[ka.lay.pe0 + d]; X[ms * 256 + d] = xr; }   // mld_denoiser.py:210
+        {
+            const int ms = tid0 >> 8, d = tid0 & 255;
+            if (tid0 < 256 * MS) { xr = LAT[d] + vp[lay->pe0 + d]; X[ms * 256 + d] = xr; }   // mld_denoiser.py:210
+        }
         __syncthreads();
 
+#pragma unroll 1
         for (int l = 0; l < SEEME_DEN_NL; ++l) {
-            const DenLayerOff& L = ka.lay.L[l];
+            const DenLayerOff* __restrict__ L = &lay->L[l];
+            // Launder the thread id once per layer: every address derived from it is then recomputed inside
+            // the layer body instead of being hoisted out of the loops (which costs >100 live VGPRs and spills).
+            int tid = tid0;
+            asm volatile("" : "+v"(tid));
+            const int ms = tid >> 8, d = tid & 255;
+            const bool own = tid < 256 * MS;
+            // condition tables of this workgroup's sample(s): CFG -> ms 0 = uncond (first half), ms 1 = cond
+            const int bc = (MS == 2) ? (ms == 0 ? b : A.B + b) : b;
+            const float* __restrict__ ct = A.ctab + (size_t)(own ? bc : b) * N * SEEME_CROW;
             // ---- skip connection: Linear(cat[x, xs.pop()])  (cross_attention.py:77-79)
             if (l >= 3) {
                 if (own) { VA[ms * 512 + d] = xr; VA[ms * 512 + 256 + d] = SK[((4 - l) * MS + ms) * 256 + d]; }
                 __syncthreads();
-                const float r = gemv256_owner<WT, MS>(wg + L.skip, 512, VA, 512, PART);
-                if (own) { xr = r + vp[L.skip_b + d]; X[ms * 256 + d] = xr; }
+                gemv_run<WT, 512, 256, MS>(tid, wg, L->skip, VA, 512, Abuf, G_INP::pre(tid, L->inp), PART);
+                const float r = owner256<MS>(tid, PART);
+                if (own) { xr = r + vp[L->skip_b + d]; X[ms * 256 + d] = xr; }
                 __syncthreads();
             }
             // ---- sa_block: post-norm encoder layer over [x, xf.., emb]; only token 0 is kept
             //      (mdiff_transformer.py:292-297); K/V of xf and emb come from the tables.
-            gemv_lds<WT, MS>(wg + L.inp, 256, 768, X, 256, vp + L.in_b, SEEME_ACT_NONE, QKV, 768, PART);
+            gemv_run<WT, 256, 768, MS>(tid, wg, L->inp, X, 256, Abuf, G_SQ::pre(tid, L->outp), PART);
+            combine_lds<WT, 256, 768, MS>(tid, PART, vp + L->in_b, SEEME_ACT_NONE, QKV, 768);
             float sc[DEN_MAXTOK];
             {
                 const float q = own ? QKV[ms * 768 + d] : 0.f;
@@ -262,25 +329,29 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             }
             __syncthreads();
             {
-                const float r = gemv256_owner<WT, MS>(wg + L.outp, 256, VB, 256, PART);
-                float v = xr + r + (own ? vp[L.out_b + d] : 0.f);
-                xr = group_ln(v, vp + L.n1w, vp + L.n1b, d, RED, cnt);
+                gemv_run<WT, 256, 256, MS>(tid, wg, L->outp, VB, 256, Abuf, G_L1::pre(tid, L->l1), PART);
+                const float r = owner256<MS>(tid, PART);
+                float v = xr + r + (own ? vp[L->out_b + d] : 0.f);
+                xr = group_ln(v, vp + L->n1w, vp + L->n1b, d, RED, cnt);
                 if (own) X[ms * 256 + d] = xr;
                 __syncthreads();
             }
-            gemv_lds<WT, MS>(wg + L.l1, 256, ff_sa, X, 256, vp + L.l1b, SEEME_ACT_RELU, VA, ff_sa, PART);
+            gemv_run<WT, 256, FF_SA, MS>(tid, wg, L->l1, X, 256, Abuf, G_L2::pre(tid, L->l2), PART);
+            combine_lds<WT, 256, FF_SA, MS>(tid, PART, vp + L->l1b, SEEME_ACT_RELU, VA, FF_SA);
             {
-                const float r = gemv256_owner<WT, MS>(wg + L.l2, ff_sa, VA, ff_sa, PART);
-                float v = xr + r + (own ? vp[L.l2b + d] : 0.f);
-                xr = group_ln(v, vp + L.n2w, vp + L.n2b, d, RED, cnt);
+                gemv_run<WT, FF_SA, 256, MS>(tid, wg, L->l2, VA, FF_SA, Abuf, G_SQ::pre(tid, L->caq), PART);
+                const float r = owner256<MS>(tid, PART);
+                float v = xr + r + (own ? vp[L->l2b + d] : 0.f);
+                xr = group_ln(v, vp + L->n2w, vp + L->n2b, d, RED, cnt);
             }
             // ---- ca_block: linear cross-attention + AdaLN (mdiff_transformer.py:219-239, 152-163)
             {
-                const float xn = group_ln(xr, vp + L.cnw, vp + L.cnb, d, RED, cnt);
+                const float xn = group_ln(xr, vp + L->cnw, vp + L->cnb, d, RED, cnt);
                 if (own) VB[ms * 256 + d] = xn;
                 __syncthreads();
-                const float r = gemv256_owner<WT, MS>(wg + L.caq, 256, VB, 256, PART);
-                float qv[1] = {own ? r + vp[L.caq_b + d] : -INFINITY};
+                gemv_run<WT, 256, 256, MS>(tid, wg, L->caq, VB, 256, Abuf, G_SQ::pre(tid, L->cao), PART);
+                const float r = owner256<MS>(tid, PART);
+                float qv[1] = {own ? r + vp[L->caq_b + d] : -INFINITY};
                 float mx[1] = {qv[0]};
                 group_seg_reduce<1, true>(mx, 1, H, RED, cnt);
                 float e[1] = {own ? expf(qv[0] - mx[0]) : 0.f};
@@ -302,28 +373,33 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
 #pragma unroll
                 for (int j = 0; j < DEN_MAXTOK - 2; ++j)
                     if (j < N) y = fmaf(dots[j], ct[(size_t)j * SEEME_CROW + 2560 + l * 512 + 256 + d], y);  // q (k^T v)  (:236-237)
-                float hh = group_ln(y, vp + L.csnw, vp + L.csnb, d, RED, cnt);
+                float hh = group_ln(y, vp + L->csnw, vp + L->csnb, d, RED, cnt);
                 hh = hh * (1.f + tt[2560 + l * 1024 + d]) + tt[2560 + l * 1024 + 256 + d];
-                __syncthreads();   // PART / VB reuse guard
                 if (own) VB[ms * 256 + d] = act_apply(hh, SEEME_ACT_SILU);
                 __syncthreads();
-                const float r2 = gemv256_owner<WT, MS>(wg + L.cao, 256, VB, 256, PART);
-                if (own) { xr = xr + r2 + vp[L.cao_b + d]; X[ms * 256 + d] = xr; }
+                gemv_run<WT, 256, 256, MS>(tid, wg, L->cao, VB, 256, Abuf, G_F1::pre(tid, L->f1), PART);
+                const float r2 = owner256<MS>(tid, PART);
+                if (own) { xr = xr + r2 + vp[L->cao_b + d]; X[ms * 256 + d] = xr; }
                 __syncthreads();
             }
             // ---- ffn + AdaLN (mdiff_transformer.py:251-254)
-            gemv_lds<WT, MS>(wg + L.f1, 256, ff, X, 256, vp + L.f1b, SEEME_ACT_GELU, VA, ff, PART);
+            gemv_run<WT, 256, FF_D, MS>(tid, wg, L->f1, X, 256, Abuf, G_F2::pre(tid, L->f2), PART);
+            combine_lds<WT, 256, FF_D, MS>(tid, PART, vp + L->f1b, SEEME_ACT_GELU, VA, FF_D);
             {
-                const float r = gemv256_owner<WT, MS>(wg + L.f2, ff, VA, ff, PART);
-                const float y2 = r + (own ? vp[L.f2b + d] : 0.f);
-                float hh = group_ln(y2, vp + L.fsnw, vp + L.fsnb, d, RED, cnt);
+                gemv_run<WT, FF_D, 256, MS>(tid, wg, L->f2, VA, FF_D, Abuf, G_SQ::pre(tid, L->fo), PART);
+                const float r = owner256<MS>(tid, PART);
+                const float y2 = r + (own ? vp[L->f2b + d] : 0.f);
+                float hh = group_ln(y2, vp + L->fsnw, vp + L->fsnb, d, RED, cnt);
                 hh = hh * (1.f + tt[2560 + l * 1024 + 512 + d]) + tt[2560 + l * 1024 + 768 + d];
-                __syncthreads();
                 if (own) VB[ms * 256 + d] = act_apply(hh, SEEME_ACT_SILU);
                 __syncthreads();
-                const float r2 = gemv256_owner<WT, MS>(wg + L.fo, 256, VB, 256, PART);
+                // the chunk requested now belongs to the next layer (or to layer 0 of the next step)
+                const int ln = (l + 1 < SEEME_DEN_NL) ? l + 1 : 0;
+                const NextPre nx = (ln >= 3) ? G_SKIP::pre(tid, lay->L[ln].skip) : G_INP::pre(tid, lay->L[ln].inp);
+                gemv_run<WT, 256, 256, MS>(tid, wg, L->fo, VB, 256, Abuf, nx, PART);
+                const float r2 = owner256<MS>(tid, PART);
                 if (own) {
-                    xr = xr + r2 + vp[L.fo_b + d];
+                    xr = xr + r2 + vp[L->fo_b + d];
                     X[ms * 256 + d] = xr;
                     if (l < 2) SK[(l * MS + ms) * 256 + d] = xr;
                 }
@@ -331,7 +407,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             }
         }
         // ---- stack norm -> model output (cross_attention.py:82-83; mld_denoiser.py:222)
-        float e = group_ln(xr, vp + ka.lay.fnw, vp + ka.lay.fnb, d, RED, cnt);
+        const int tid = tid0, ms = tid >> 8, d = tid & 255;
+        const bool own = tid < 256 * MS;
+        float e = group_ln(xr, vp + lay->fnw, vp + lay->fnb, d, RED, cnt);
         if (MS == 2) {   // classifier-free guidance (mld.py:488-492), uncond first
             __syncthreads();
             if (own) VB[ms * 256 + d] = e;
@@ -340,7 +418,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
         }
         if (A.sched == SEEME_SCHED_NONE) {
             if (tid < 256) A.out[(size_t)b * 256 + d] = e;
-            return;   // steps == 1 by contract
+            break;   // steps == 1 by contract
         }
         // ---- scheduler.step (mld.py:495-497; scalars prepared by seeme_amd/schedulers.py)
         if (tid < 256) {
@@ -356,17 +434,18 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
         }
         __syncthreads();
     }
-    if (tid < 256) A.out[(size_t)b * 256 + d] = LAT[d];
+    if (A.sched != SEEME_SCHED_NONE && tid0 < 256) A.out[(size_t)b * 256 + tid0] = LAT[tid0];
+    // the last requested chunk is never consumed: keep it from being optimised into a dangling load
+    asm volatile("" ::"v"(Abuf.r[0].x));
 }
 
-static size_t den_lds_bytes(int MS, int ff_sa) {
-    const int vmax = ff_sa > 512 ? ff_sa : 512;
-    return (size_t)(MS * 256 + 256 + 2 * MS * 256 + MS * vmax + MS * 256 + MS * 768 + 4 * MS * 256 + 128) * sizeof(float);
+static size_t den_lds_bytes(int MS) {
+    return (size_t)(MS * 256 + 256 + 2 * MS * 256 + MS * FF_SA + MS * 256 + MS * 768 + 2 * MS * 768 + 128) * sizeof(float);
 }
 
 template <typename WT, int MS>
 static int launch_den(const DenKArgs& ka, hipStream_t st) {
-    const size_t lds = den_lds_bytes(MS, ka.ff_sa);
+    const size_t lds = den_lds_bytes(MS);
     SEEME_HIP(hipFuncSetAttribute((const void*)k_den_sample<WT, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_den_sample<WT, MS>), dim3(ka.s.B), dim3(DEN_THREADS), lds, st, ka);
     return seeme_check_launch("k_den_sample");
@@ -376,12 +455,17 @@ extern "C" int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeS
     if (a->B <= 0) return seeme_fail("denoiser_sample: B must be > 0");
     if (a->N < 1 || a->N > DEN_MAXTOK - 2) return seeme_fail("denoiser_sample: 1 <= N <= 4 condition tokens");
     if (w->nhead != 1 && w->nhead != 2 && w->nhead != 4) return seeme_fail("denoiser_sample: nhead must be 1, 2 or 4");
-    if (w->ff_sa % 512 != 0 || w->ff % 64 != 0 || w->ff > 512) return seeme_fail("denoiser_sample: unsupported ff sizes");
+    if (w->ff_sa != FF_SA || w->ff != FF_D) return seeme_fail("denoiser_sample: built for sa ff 1024 / ffn_dim 128 (all reference configs)");
+    if (w->layout == nullptr) return seeme_fail("denoiser_sample: layout table missing");
     if (a->sched == SEEME_SCHED_NONE && a->steps != 1) return seeme_fail("denoiser_sample: SCHED_NONE needs steps == 1");
     if (a->steps < 1) return seeme_fail("denoiser_sample: steps must be >= 1");
     DenKArgs ka;
-    ka.wg = w->wg; ka.vp = w->vp; ka.lay = seeme_make_den_layout(w->ff_sa, w->ff);
-    ka.nhead = w->nhead; ka.ff_sa = w->ff_sa; ka.ff = w->ff; ka.s = *a;
+    ka.wg = w->wg; ka.vp = w->vp; ka.lay = reinterpret_cast<const DenLayout*>(w->layout);
+    {
+        const DenLayout hl = seeme_make_den_layout(FF_SA, FF_D);
+        ka.wg_bytes = (int)(hl.wg_total * (w->wdtype == 0 ? 4 : 2));
+    }
+    ka.nhead = w->nhead; ka.s = *a;
     hipStream_t st = (hipStream_t)stream;
     if (w->wdtype == 0) return a->cfg ? launch_den<WF32, 2>(ka, st) : launch_den<WF32, 1>(ka, st);
     if (w->wdtype == 1) return a->cfg ? launch_den<WBF16, 2>(ka, st) : launch_den<WBF16, 1>(ka, st);

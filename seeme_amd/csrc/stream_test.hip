@@ -1,0 +1,78 @@
+// stream_test.hip -- micro-benchmark / correctness probe for the per-wave LDS-DMA weight ring used by
+// the sampling kernel (debug entry point, not part of the product path).
+//
+// Every workgroup streams the SAME `bytes` (like the shared weight image): wave w consumes 1 KiB
+// pieces j*NW + w.  mode 0: plain register loads (8 deep); mode 1: private LDS ring filled by
+// global_load_lds_dwordx4 (inline asm, hand-counted vmcnt), R pieces ahead.
+#include "common.hpp"
+#include "api_util.hpp"
+#include "lds_ring.hpp"
+
+template <int R>
+__global__ __launch_bounds__(512) void k_stream_ring(const float4* __restrict__ src, long npw, int reps,
+                                                     float* __restrict__ out) {
+    const long npieces_per_wave = npw * reps;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int NW = blockDim.x >> 6;
+    float* ring = smem + wave * (R * 256);                       // R slots x 1 KiB per wave
+    const uint32_t ring_lds = lds_addr_of(ring);
+    const float4* my = src + (size_t)wave * 64 + lane;            // piece j -> my + j*NW*64
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // prologue: R pieces in flight
+    for (int j = 0; j < R; ++j)
+        if (j < npieces_per_wave) lds_dma_1k(my + (size_t)(j % npw) * NW * 64, ring_lds + (uint32_t)j * 1024u);
+    for (long j = 0; j < npieces_per_wave; ++j) {
+        const int slot = (int)(j % R);
+        // pieces issued after piece j: min(R-1, remaining) -> wait until at most that many are outstanding
+        const long younger = (npieces_per_wave - 1 - j) < (R - 1) ? (npieces_per_wave - 1 - j) : (R - 1);
+        wait_vmcnt_dyn<R>((int)younger);
+        const float4 w = *reinterpret_cast<const float4*>(ring + slot * 256 + lane * 4);
+        acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
+        if (j + R < npieces_per_wave)
+            lds_dma_1k_after_read(my + (size_t)((j + R) % npw) * NW * 64, ring_lds + (uint32_t)slot * 1024u);
+    }
+    wait_vmcnt0();
+    out[(size_t)blockIdx.x * blockDim.x + tid] = (acc.x + acc.y) + (acc.z + acc.w);
+}
+
+__global__ __launch_bounds__(512) void k_stream_regs(const float4* __restrict__ src, long npieces_per_wave, int reps,
+                                                     float* __restrict__ out) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int NW = blockDim.x >> 6;
+    const float4* my = src + (size_t)wave * 64 + lane;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int rep = 0; rep < reps; ++rep) {
+    long j = 0;
+#pragma unroll 1
+    for (; j + 16 <= npieces_per_wave; j += 16) {
+        float4 w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = my[(size_t)(j + i) * NW * 64];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc.x += w[i].x; acc.y += w[i].y; acc.z += w[i].z; acc.w += w[i].w; }
+    }
+    for (; j < npieces_per_wave; ++j) { const float4 w = my[(size_t)j * NW * 64]; acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w; }
+  }
+    out[(size_t)blockIdx.x * blockDim.x + tid] = (acc.x + acc.y) + (acc.z + acc.w);
+}
+
+extern "C" int seeme_debug_stream(const float* src, long bytes, int reps, int mode, int ring, int blocks, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int NW = 8;
+    const long npw = bytes / 1024 / NW;
+    if (npw <= 0) return seeme_fail("debug_stream: too few bytes");
+    if (mode == 0) {
+        hipLaunchKernelGGL(k_stream_regs, dim3(blocks), dim3(512), 0, st, (const float4*)src, npw, reps, out);
+    } else if (ring == 8) {
+        const size_t lds = (size_t)NW * 8 * 1024;
+        hipLaunchKernelGGL((k_stream_ring<8>), dim3(blocks), dim3(512), lds, st, (const float4*)src, npw, reps, out);
+    } else if (ring == 16) {
+        const size_t lds = (size_t)NW * 16 * 1024;
+        SEEME_HIP(hipFuncSetAttribute((const void*)k_stream_ring<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_stream_ring<16>), dim3(blocks), dim3(512), lds, st, (const float4*)src, npw, reps, out);
+    } else {
+        return seeme_fail("debug_stream: ring must be 8 or 16");
+    }
+    return seeme_check_launch("k_stream");
+}

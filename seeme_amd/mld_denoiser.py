@@ -161,6 +161,7 @@ class MldDenoiser(nn.Module):
         vals = list(buf)
         layers = [dict(zip(_LAYER_FIELDS, vals[i * 30:(i + 1) * 30])) for i in range(5)]
         pe0, fnw, fnb, wg_total, vp_total = vals[150:155]
+        self._layout_vals = vals
         return layers, pe0, fnw, fnb, wg_total, vp_total
 
     def _weights(self):
@@ -216,8 +217,9 @@ class MldDenoiser(nn.Module):
                               for b in blocks]).contiguous()
             ca_w = [torch.cat([b.ca_block.key.weight, b.ca_block.value.weight]).contiguous() for b in blocks]
             ca_b = [torch.cat([b.ca_block.key.bias, b.ca_block.value.bias]).contiguous() for b in blocks]
+        lay_dev = torch.tensor(self._layout_vals, dtype=torch.int64, device=dev)
         w = L.DenoiserWeights()
-        w.wg, w.wdtype, w.vp = wg.data_ptr(), 1 if bf16 else 0, vp.data_ptr()
+        w.wg, w.wdtype, w.vp, w.layout = wg.data_ptr(), 1 if bf16 else 0, vp.data_ptr(), lay_dev.data_ptr()
         w.nhead, w.ff_sa, w.ff = self.num_heads, 1024, self.ff_size
         w.kv_cat_w, w.kv_cat_b, w.style_cat_w, w.style_cat_b = kv_w.data_ptr(), kv_b.data_ptr(), st_w.data_ptr(), st_b.data_ptr()
         te = self.time_embedding
@@ -226,7 +228,7 @@ class MldDenoiser(nn.Module):
         for l, b in enumerate(blocks):
             w.ca_kv_w[l], w.ca_kv_b[l] = ca_w[l].data_ptr(), ca_b[l].data_ptr()
             w.ca_tn_w[l], w.ca_tn_b[l] = L.ptr(b.ca_block.text_norm.weight), L.ptr(b.ca_block.text_norm.bias)
-        self._wcache = (fpnt, w, (wg, vp, kv_w, kv_b, st_w, st_b, ca_w, ca_b))
+        self._wcache = (fpnt, w, (wg, vp, kv_w, kv_b, st_w, st_b, ca_w, ca_b, lay_dev))
         self._table_cache = {}
         return w
 
