@@ -195,6 +195,31 @@ int seeme_smpl_lbs(const SeemeSmplModel* m, const float* betas, const float* pos
                    const float* transl, int M, float* joints, float* vertices,
                    void* workspace, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ rotation helpers / renorm
+ * mld/utils/geometry2.py: aa_to_quat :33-54, aa_to_rotmat :56-72, quat_to_rotmat :74-95,
+ * rot6d_to_rotmat :98-117 ('prohmr' / 'diffusion' column order).  in [M,3|4|6] -> out [M,4] or [M,3,3]. */
+enum { SEEME_GEO_AA_TO_QUAT = 0, SEEME_GEO_AA_TO_ROTMAT = 1, SEEME_GEO_QUAT_TO_ROTMAT = 2,
+       SEEME_GEO_ROT6D_PROHMR = 3, SEEME_GEO_ROT6D_DIFFUSION = 4 };
+int seeme_geometry(int op, const float* in, float* out, int M, void* stream);
+/* EgoBodyDataModule.renorm (mld/data/EgoBody.py:151-157): y = x * std[:F] + mean[:F], x [rows,F]. */
+int seeme_renorm(const float* x, const float* mean, const float* stdv, float* y, long rows, int F, void* stream);
+
+/* ------------------------------------------------------------------ PointNet scene encoder
+ * EgoHMR.models.respointnet.ResnetPointnet(out_dim, hidden 256) (respointnet.py:6-59); PyTorch-layout
+ * fp32 weights, fc_pos_0.weight zero padded to [512,16]. */
+typedef struct {
+    int out_dim;                          /* 512 */
+    const float* pos_w; const float* pos_b;          /* fc_pos_0 [512,16 padded], [512] */
+    const float* fc0_w[4]; const float* fc0_b[4];    /* block_i.fc_0 [256,512] */
+    const float* fc1_w[4]; const float* fc1_b[4];    /* block_i.fc_1 [256,256] */
+    const float* sc_w[4];                            /* block_i.shortcut [256,512], no bias */
+    const float* fcc_w; const float* fcc_b;          /* fc_c [out_dim,256] */
+} SeemePointnetWeights;
+size_t seeme_pointnet_workspace_bytes(int B, int P);
+/* points [B,P,3] -> out [B,out_dim] */
+int seeme_pointnet_encode(const SeemePointnetWeights* w, const float* points, int B, int P, float* out,
+                          void* workspace, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,13 @@ class SmplModel(C.Structure):
                 ("ex_posedirs", fp), ("ex_weights", fp)]
 
 
+class PointnetWeights(C.Structure):
+    _fields_ = [("out_dim", C.c_int), ("pos_w", fp), ("pos_b", fp), ("fc0_w", fp * 4), ("fc0_b", fp * 4),
+                ("fc1_w", fp * 4), ("fc1_b", fp * 4), ("sc_w", fp * 4), ("fcc_w", fp), ("fcc_b", fp)]
+
+
+GEO_AA_TO_QUAT, GEO_AA_TO_ROTMAT, GEO_QUAT_TO_ROTMAT, GEO_ROT6D_PROHMR, GEO_ROT6D_DIFFUSION = range(5)
+
 # name -> (restype, argtypes); every symbol of include/seeme_hip.h
 _SIGNATURES = {
     "seeme_version": (C.c_int, []),
@@ -83,6 +90,10 @@ _SIGNATURES = {
     "seeme_denoiser_cond_tables": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
     "seeme_denoiser_sample": (C.c_int, [C.POINTER(DenoiserWeights), C.POINTER(SampleArgs), fp]),
     "seeme_den_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "seeme_geometry": (C.c_int, [C.c_int, fp, fp, C.c_int, fp]),
+    "seeme_renorm": (C.c_int, [fp, fp, fp, fp, C.c_long, C.c_int, fp]),
+    "seeme_pointnet_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "seeme_pointnet_encode": (C.c_int, [C.POINTER(PointnetWeights), fp, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
     "seeme_smpl_workspace_bytes": (C.c_size_t, [C.c_int]),
     "seeme_smpl_lbs": (C.c_int, [C.POINTER(SmplModel), fp, fp, C.c_int, fp, C.c_int, fp, fp, fp, C.c_size_t, fp]),
 }

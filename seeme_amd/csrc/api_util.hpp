@@ -15,6 +15,20 @@ int seeme_check_launch(const char* kernel);      // hipGetLastError after a laun
     } while (0)
 
 // shared between translation units
+#include "../../include/seeme_hip.h"
+struct LinearKArgs {
+    SeemeLinearArgs a;
+    // optional row remapping (sequence-structured tensors)
+    int seq_in;      // logical rows per sequence (0 = identity mapping everywhere)
+    int in_stride;   // physical rows per sequence of A   (A row = (m/seq_in)*in_stride + m%seq_in + in_off)
+    int in_off;
+    int out_stride;  // physical rows per sequence of Y
+    int out_off;
+    int res_mode;      // 0: residual row = output row; 1: (m % seq_in) + res_off (positional embedding add);
+                       // 2: m / seq_in (one row per sequence: broadcast vector)
+    int res_off;
+};
+int seeme_launch_linear(const LinearKArgs& ka, hipStream_t st);
 int seeme_linear_simple(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias,
                         float* Y, int ldy, int M, int N, int K, int act, int pre_act,
                         const float* pre_ln_w, const float* pre_ln_b);

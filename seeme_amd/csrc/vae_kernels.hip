@@ -9,17 +9,7 @@
 
 // ---------------------------------------------------------------------------------------------
 // k_linear: Y = LN?( act( pre(A|A2) W^T + bias ) + res ), one 32-row x 256-col tile per workgroup.
-struct LinearKArgs {
-    SeemeLinearArgs a;
-    // optional row remapping (sequence-structured tensors)
-    int seq_in;      // logical rows per sequence (0 = identity mapping everywhere)
-    int in_stride;   // physical rows per sequence of A   (A row = (m/seq_in)*in_stride + m%seq_in + in_off)
-    int in_off;
-    int out_stride;  // physical rows per sequence of Y
-    int out_off;
-    int res_periodic;  // 1: residual row = (m % seq_in) + res_off  (positional embedding add)
-    int res_off;
-};
+
 
 __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -87,7 +77,8 @@ __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
         const int c = lane * 4, g = cn0 + c;
         float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + c);
         if (a.res != nullptr) {
-            const size_t rrow = ka.res_periodic ? (size_t)((m % ka.seq_in) + ka.res_off) : (size_t)orow;
+            const size_t rrow = ka.res_mode == 1 ? (size_t)((m % ka.seq_in) + ka.res_off)
+                              : ka.res_mode == 2 ? (size_t)(m / ka.seq_in) : (size_t)orow;
             const float* rp = a.res + rrow * a.ldr + g;
             if (g + 0 < a.N) v.x += rp[0];
             if (g + 1 < a.N) v.y += rp[1];
@@ -107,7 +98,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
     }
 }
 
-static int launch_linear(const LinearKArgs& ka, hipStream_t st) {
+int seeme_launch_linear(const LinearKArgs& ka, hipStream_t st) {
     const SeemeLinearArgs& a = ka.a;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return seeme_fail("seeme_linear: empty problem");
     if (a.ln_w && a.N != 256) return seeme_fail("seeme_linear: fused LayerNorm needs N == 256");
@@ -127,7 +118,7 @@ extern "C" int seeme_linear(const SeemeLinearArgs* args, void* stream) {
     LinearKArgs ka{};
     ka.a = *args;
     if (ka.a.A2 == nullptr) ka.a.K1 = ka.a.K;
-    return launch_linear(ka, (hipStream_t)stream);
+    return seeme_launch_linear(ka, (hipStream_t)stream);
 }
 
 // convenience for the host sequencers
@@ -139,7 +130,7 @@ static int linear_simple(hipStream_t st, const float* A, int lda, const float* W
     ka.a.A = A; ka.a.lda = lda; ka.a.K1 = K; ka.a.W = W; ka.a.ldw = ldw; ka.a.bias = bias;
     ka.a.Y = Y; ka.a.ldy = ldy; ka.a.M = M; ka.a.N = N; ka.a.K = K; ka.a.act = act; ka.a.pre_act = pre_act;
     ka.a.pre_ln_w = pre_ln_w; ka.a.pre_ln_b = pre_ln_b; ka.a.eps = 1e-5f;
-    return launch_linear(ka, st);
+    return seeme_launch_linear(ka, st);
 }
 int seeme_linear_simple(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias,
                         float* Y, int ldy, int M, int N, int K, int act, int pre_act,
@@ -425,7 +416,7 @@ static int skip_linear(hipStream_t st, const float* a1, const float* a2, const f
     LinearKArgs ka{};
     ka.a.A = a1; ka.a.lda = 256; ka.a.A2 = a2; ka.a.lda2 = 256; ka.a.K1 = 256; ka.a.K = 512;
     ka.a.W = w; ka.a.ldw = 512; ka.a.bias = b; ka.a.Y = y; ka.a.ldy = 256; ka.a.M = M; ka.a.N = 256; ka.a.eps = 1e-5f;
-    return launch_linear(ka, st);
+    return seeme_launch_linear(ka, st);
 }
 
 extern "C" int seeme_vae_encode(const SeemeVaeWeights* w, const float* features, const int32_t* lengths,
@@ -449,8 +440,8 @@ extern "C" int seeme_vae_encode(const SeemeVaeWeights* w, const float* features,
         ka.a.bias = w->emb_b; ka.a.res = w->pe_enc; ka.a.ldr = 256; ka.a.Y = ws.x; ka.a.ldy = 256;
         ka.a.M = B * T; ka.a.N = 256; ka.a.eps = 1e-5f;
         ka.seq_in = T; ka.in_stride = T; ka.in_off = 0; ka.out_stride = S; ka.out_off = 2;
-        ka.res_periodic = 1; ka.res_off = 2;
-        rc = launch_linear(ka, st);
+        ka.res_mode = 1; ka.res_off = 2;
+        rc = seeme_launch_linear(ka, st);
         if (rc) return rc;
     }
     const int ff = w->ff, act = SEEME_ACT_GELU;

@@ -1,0 +1,72 @@
+"""ResnetPointnet -- drop-in for ``EgoHMR.models.respointnet.ResnetPointnet`` (respointnet.py:6-97), the
+frozen scene encoder MLD consumes through ``ProHMRScene.encode_scene`` (prohmr_scene.py:102-104;
+mld/models/modeltype/mld.py:911-922).  Same parameter names (``fc_pos_0``, ``block_{0..3}.{fc_0,fc_1,shortcut}``,
+``fc_c``) so the ``proscene.scene_enc.*`` entries of a checkpoint load; forward runs in libseeme_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .mld_vae import _param_fingerprint
+
+
+class _ResnetBlockFCParams(nn.Module):
+    def __init__(self, size_in, size_out, size_h):
+        super().__init__()
+        self.fc_0 = nn.Linear(size_in, size_h)
+        self.fc_1 = nn.Linear(size_h, size_out)
+        self.shortcut = nn.Linear(size_in, size_out, bias=False)
+        nn.init.zeros_(self.fc_1.weight)            # respointnet.py:86
+
+
+class ResnetPointnet(nn.Module):
+    def __init__(self, out_dim: int = 512, hidden_dim: int = 256):
+        super().__init__()
+        if hidden_dim != 256:
+            raise NotImplementedError("accelerated path: hidden_dim 256 (ProHMRScene builds ResnetPointnet(512, 256))")
+        self.out_dim = out_dim
+        self.fc_pos_0 = nn.Linear(3, 2 * hidden_dim)
+        for i in range(4):
+            setattr(self, f"block_{i}", _ResnetBlockFCParams(2 * hidden_dim, hidden_dim, hidden_dim))
+        self.fc_c = nn.Linear(hidden_dim, out_dim)
+        self._wcache = None
+        self._ws = None
+
+    def _weights(self):
+        fpnt = _param_fingerprint(self)
+        if self._wcache is not None and self._wcache[0] == fpnt:
+            return self._wcache[1]
+        for p in self.parameters():
+            L.require_cuda(p, "ResnetPointnet parameter")
+        with torch.no_grad():
+            posw = torch.zeros(512, 16, device=self.fc_pos_0.weight.device, dtype=torch.float32)
+            posw[:, :3] = self.fc_pos_0.weight
+        w = L.PointnetWeights()
+        w.out_dim = self.out_dim
+        w.pos_w, w.pos_b = posw.data_ptr(), L.ptr(self.fc_pos_0.bias)
+        for i in range(4):
+            blk = getattr(self, f"block_{i}")
+            w.fc0_w[i], w.fc0_b[i] = L.ptr(blk.fc_0.weight), L.ptr(blk.fc_0.bias)
+            w.fc1_w[i], w.fc1_b[i] = L.ptr(blk.fc_1.weight), L.ptr(blk.fc_1.bias)
+            w.sc_w[i] = L.ptr(blk.shortcut.weight)
+        w.fcc_w, w.fcc_b = L.ptr(self.fc_c.weight), L.ptr(self.fc_c.bias)
+        self._wcache = (fpnt, w, (posw,))
+        return w
+
+    def forward(self, p: torch.Tensor) -> torch.Tensor:
+        """p [B, n_pts, 3] -> [B, out_dim]."""
+        L.require_cuda(p, "points")
+        B, P, three = p.shape
+        assert three == 3
+        p = p.contiguous()
+        out = torch.empty(B, self.out_dim, device=p.device, dtype=torch.float32)
+        need = L.lib().seeme_pointnet_workspace_bytes(B, P)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != p.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=p.device)
+        w = self._weights()
+        L.check(L.lib().seeme_pointnet_encode(C.byref(w), p.data_ptr(), B, P, out.data_ptr(), self._ws.data_ptr(),
+                                               self._ws.numel(), L.current_stream()), "seeme_pointnet_encode")
+        return out

@@ -267,3 +267,31 @@ def test_smpl_lbs(dev, rotmat):
     # index bookkeeping is exact (BASELINE.json: joint/vertex indices bit-exact)
     assert smpl.parents.tolist() == O.SMPL_PARENTS.tolist()
     assert smpl.vertex_joint_selector.extra_joints_idxs.tolist() == O.SMPL_EXTRA_VERTEX_IDS.tolist()
+
+
+# ----------------------------------------------------------------------------- geometry / PointNet
+def test_geometry_golden(dev):
+    from seeme_amd import geometry as G
+    g = load_golden("misc.npz")
+    aa, r6 = torch.from_numpy(g["aa"]).to(dev), torch.from_numpy(g["rot6d"]).to(dev)
+    assert rel_err(G.aa_to_quat(aa).cpu().numpy(), g["aa_to_quat"]) < 1e-5
+    assert rel_err(G.aa_to_rotmat(aa).cpu().numpy(), g["aa_to_rotmat"]) < 1e-5
+    assert rel_err(G.rot6d_to_rotmat(r6).cpu().numpy(), g["rot6d_to_rotmat"]) < 1e-5
+    assert rel_err(G.rot6d_to_rotmat(r6, "diffusion").cpu().numpy(), O.rot6d_to_rotmat(g["rot6d"], "diffusion")) < 1e-5
+    q = torch.randn(33, 4, device=dev)
+    assert rel_err(G.quat_to_rotmat(q).cpu().numpy(), O.quat_to_rotmat(q.cpu().numpy())) < 1e-5
+    x = torch.randn(3, 7, 75, device=dev)
+    mean, std = torch.randn(1, 90), torch.rand(1, 90) + 0.5
+    assert rel_err(G.renorm(x, mean, std).cpu().numpy(), O.renorm(x.cpu().numpy(), mean.numpy(), std.numpy())) < 1e-6
+
+
+def test_pointnet_golden(dev):
+    from seeme_amd.respointnet import ResnetPointnet
+    g = load_golden("misc.npz")
+    pn = load_recipe_(ResnetPointnet(512, 256)).to(dev).eval()
+    out = pn(torch.from_numpy(g["points"]).to(dev))
+    assert rel_err(out.cpu().numpy(), g["pointnet"]) < TOL_F32
+    # ragged point count (not a multiple of the 32-row tile) against the oracle
+    pts = np.random.default_rng(2).uniform(-3, 3, (3, 777, 3)).astype(np.float32)
+    P = recipe_state_dict(shapes.pointnet_shapes())
+    assert rel_err(pn(torch.from_numpy(pts).to(dev)).cpu().numpy(), O.pointnet_forward(P, pts)) < TOL_F32
