@@ -1,0 +1,97 @@
+"""Data-parallel plumbing: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI on
+ROCm, "gloo" for CPU tests).  The reference gets all of this implicitly from Lightning's
+``strategy="ddp"`` (train.py:127-131); the path needs exactly two things:
+
+* sampling: sequences are independent -> contiguous shards per rank, NO collective on the data path;
+  only the few metric sums are reduced at the end (C2);
+* training: one mean all-reduce of the trainable gradients per step (C1: denoiser 7.90 M + output_scene
+  0.13 M parameters = 32 MB fp32) as ONE flat bucket, so RCCL sees a single large message.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def world() -> Tuple[int, int]:
+    return (dist.get_rank(), dist.get_world_size()) if is_dist() else (0, 1)
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+    """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torch.distributed.run)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if ws > 1 and not is_dist():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=ws)
+    return rank, ws, local
+
+
+def shard_range(n: int, rank: int = None, ws: int = None) -> Tuple[int, int]:
+    """Contiguous, balanced [lo, hi) of `n` independent sequences for this rank (ranks differ by <= 1)."""
+    if rank is None:
+        rank, ws = world()
+    base, rem = divmod(n, ws)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = True) -> int:
+    """Mean all-reduce of every .grad as one flat bucket; parameters without a gradient (e.g. mem_pos.pe,
+    which trans_enc never touches) contribute zeros so that all ranks agree on the layout.
+    Returns the number of elements reduced."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return 0
+    rank, ws = world()
+    if ws == 1:
+        return sum(p.numel() for p in params)
+    dev, dt = params[0].device, torch.float32
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dt) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= ws
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off:off + n].view_as(p).to(p.dtype)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n
+    return int(flat.numel())
+
+
+def reduce_sums(t: torch.Tensor) -> torch.Tensor:
+    """Sum a small tensor of metric / loss accumulators over ranks (dist_reduce_fx="sum" in the reference's
+    torchmetrics states, metrics/compute.py:106-178)."""
+    if not is_dist():
+        return t
+    backend = dist.get_backend()
+    x = t.clone().to("cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(x, op=dist.ReduceOp.SUM)
+    return x.to(t.device)
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0):
+    """Make every rank start from rank `src`'s weights (DDP does this at construction)."""
+    if not is_dist():
+        return
+    for p in module.parameters():
+        dist.broadcast(p.data, src)
+    for b in module.buffers():
+        dist.broadcast(b.data, src)

@@ -1,0 +1,468 @@
+"""MLD -- the orchestration class of the path, with the method surface of
+``mld.models.modeltype.mld.MLD`` / ``base.BaseModel`` (reference mld.py:88-2130, base.py:38-213) but
+without Lightning: ``training_step / validation_step / test_step / allsplit_step``,
+``_diffusion_reverse``, ``_diffusion_process``, ``train_diffusion_forward``, ``train_vae_forward``,
+``ego_eval``, ``forward`` / ``sample``, ``configure_optimizers``.
+
+What runs where
+  * VAE encode/decode, the whole reverse-diffusion loop, the denoiser forward, PointNet, SMPL, rotation
+    helpers and renorm run in libseeme_hip.so (HIP kernels for gfx950).
+  * Stage-2 *training* needs d(loss)/d(denoiser weights): this round the backward pass is PyTorch-ROCm
+    autograd over ``denoiser_autograd.denoiser_forward_torch`` (same parameters, checked against the HIP
+    forward in tests); the frozen parts of the step (VAE encodes, PointNet) are HIP.  Stage-1 (VAE)
+    training is not accelerated yet: ``train_vae_forward`` produces the forward quantities only.
+  * Only the live flows are implemented; the reference's dead code (``forward`` calling the undefined
+    ``feats2joints``, t2m_eval, the ``save_for_edo`` debug dump -- SURVEY.md App. D) is not reproduced:
+    ``forward``/``sample`` = what ``ego_eval`` really does (condition -> reverse diffusion -> decode).
+"""
+from __future__ import annotations
+
+import inspect
+import time
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import geometry as G
+from .config import instantiate_from_config
+from .denoiser_autograd import denoiser_forward_torch
+from .respointnet import ResnetPointnet
+from .smpl import SMPL
+
+
+# ----------------------------------------------------------------------------- losses / metrics
+class MLDLosses:
+    """mld/models/losses/mld.py:10-176 without torchmetrics: running sums + the weighted total."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.stage = cfg.TRAIN.STAGE
+        self.predict_epsilon = cfg.TRAIN.ABLATION.PREDICT_EPSILON
+        self.predict_transl = cfg.TRAIN.ABLATION.PREDICT_TRANSL
+        if self.stage not in ("vae", "diffusion", "vae_diffusion"):
+            raise ValueError(f"Stage {self.stage} not supported")
+        self.sums: Dict[str, float] = {}
+        self.count = 0
+
+    def _acc(self, name, val, weight):
+        self.sums[name] = self.sums.get(name, 0.0) + float(val.detach())
+        return weight * val
+
+    @staticmethod
+    def align_root(gt, pred):
+        pg, pp = gt[:, :, [0]], pred[:, :, [0]]
+        return gt - pg, pred - pp, pg, pp
+
+    def update(self, rs):
+        L = self.cfg.LOSS
+        total = 0.0
+        mse = nn.functional.mse_loss
+        sl1 = nn.functional.smooth_l1_loss
+        if self.stage in ("vae", "vae_diffusion"):
+            jr, jp = rs["joints_ref"], rs["joints_rst"]
+            if self.predict_transl:
+                jr, jp, pg, pp = self.align_root(jr, jp)
+                total = total + self._acc("recons_transl", sl1(pp, pg), L.LAMBDA_ROOT)
+            total = total + self._acc("recons_feature", sl1(rs["m_rst"], rs["m_ref"]), L.LAMBDA_REC)
+            total = total + self._acc("recons_joints", sl1(jp, jr), L.get("LAMBDA_JOINT", 1.0))
+            if L.LAMBDA_KL != 0.0:
+                kl = torch.distributions.kl_divergence(rs["dist_m"], rs["dist_ref"]).mean()
+                total = total + self._acc("kl_motion", kl, L.LAMBDA_KL)
+        if self.stage in ("diffusion", "vae_diffusion"):
+            if self.predict_epsilon:
+                total = total + self._acc("inst_loss", mse(rs["noise_pred"], rs["noise"]), 1.0)
+            else:
+                total = total + self._acc("x_loss", mse(rs["pred"], rs["latent"]), 1.0)
+        self.sums["total"] = self.sums.get("total", 0.0) + float(total.detach())
+        self.count += 1
+        return total
+
+    def compute(self):
+        return {k: v / max(self.count, 1) for k, v in self.sums.items()}
+
+    def reset(self):
+        self.sums, self.count = {}, 0
+
+
+class EgoMetrics:
+    """MPJPE / root error with the reference's alignment (metrics/compute.py:364-399, 470-473):
+    subtract the first-frame head (joint 15) position, then the per-frame pelvis; x1000 (mm);
+    per-sequence means averaged over sequences (:196).  Sums are plain tensors so that the
+    multi-GPU reduction is one small all-reduce (seeme_amd.distributed.reduce_sums)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.mpjpe_sum = 0.0
+        self.root_sum = 0.0
+        self.n_seq = 0
+
+    @staticmethod
+    def per_sequence(jts_pred, jts_ref, lengths):
+        ref = jts_ref - jts_ref[:, 0:1, 15:16, :]
+        pred = jts_pred - jts_pred[:, 0:1, 15:16, :]
+        pelvis_ref, pelvis_pred = ref[:, :, [0]], pred[:, :, [0]]
+        ref, pred = ref - pelvis_ref, pred - pelvis_pred
+        T = ref.shape[1]
+        lens = torch.as_tensor(lengths, device=ref.device)
+        mask = (torch.arange(T, device=ref.device)[None, :] < lens[:, None]).float()
+        err = (pred - ref).norm(dim=-1).mean(dim=-1)                  # [B,T]
+        mpjpe = (err * mask).sum(1) / lens * 1000.0
+        rerr = (pelvis_pred - pelvis_ref).norm(dim=-1).squeeze(-1)
+        root = (rerr * mask).sum(1) / lens * 1000.0
+        return mpjpe, root
+
+    def update(self, jts_pred, jts_ref, lengths):
+        mpjpe, root = self.per_sequence(jts_pred, jts_ref, lengths)
+        self.mpjpe_sum += float(mpjpe.sum())
+        self.root_sum += float(root.sum())
+        self.n_seq += int(mpjpe.numel())
+
+    def sums(self):
+        return torch.tensor([self.mpjpe_sum, self.root_sum, float(self.n_seq)], dtype=torch.float64)
+
+    def compute(self, sums=None):
+        s = self.sums() if sums is None else sums
+        n = max(float(s[2]), 1.0)
+        return {"MPJPE": float(s[0]) / n, "ROOT_ERROR": float(s[1]) / n}
+
+
+class SyntheticEgoDataModule:
+    """Batches with the EgoBody/GIMO tuple layout (mld/data/humanml/data/dataset.py:1754-1794): motion
+    [B,T,2,72], transl [B,2,T,3], beta [B,2,T,10], utils [B,T,6], scene [B,P,3], length [B,1]; mean/std
+    for ``renorm`` (mld/data/EgoBody.py:151-157).  Datasets are licence-gated, so this is what tests and
+    benchmarks run on."""
+
+    def __init__(self, nfeats=75, T=196, n_points=2048, seed=1234, device="cpu"):
+        self.nfeats, self.T, self.n_points = nfeats, T, n_points
+        g = torch.Generator().manual_seed(seed)
+        self.mean = (0.1 * torch.randn(1, nfeats + 16, generator=g)).to(device)
+        self.std = (0.5 + torch.rand(1, nfeats + 16, generator=g)).to(device)
+        self.device = device
+        self.is_mm = False
+        self.seed = seed
+
+    def renorm(self, features):
+        return G.renorm(features, self.mean, self.std)
+
+    def batch(self, B, idx=0, with_scene=False, lengths=None):
+        g = torch.Generator().manual_seed(self.seed * 7919 + idx)
+        T = self.T
+        motion = 0.5 * torch.randn(B, T, 2, 72, generator=g)
+        transl = torch.randn(B, 2, T, 3, generator=g)
+        beta = 0.5 * torch.randn(B, 2, 1, 10, generator=g).expand(B, 2, T, 10).contiguous()
+        utils_ = torch.zeros(B, T, 6)
+        length = torch.full((B, 1), T, dtype=torch.long) if lengths is None else torch.as_tensor(lengths).reshape(B, 1)
+        dev = self.device
+        out = [motion.to(dev), transl.to(dev), beta.to(dev), utils_.to(dev)]
+        if with_scene:
+            out.append((torch.rand(B, self.n_points, 3, generator=g) * 6 - 3).to(dev))
+        out.append(length.to(dev))
+        if with_scene:
+            out.append([])          # img_path / dict_images slot
+        return tuple(out)
+
+
+# ----------------------------------------------------------------------------- the model
+class _SceneEncoderHolder(nn.Module):
+    """``proscene.scene_enc`` -- only this sub-module of ProHMRScene is on the path (prohmr_scene.py:102-104)."""
+
+    def __init__(self):
+        super().__init__()
+        self.scene_enc = ResnetPointnet(512, 256)
+
+    def encode_scene(self, scene):
+        return self.scene_enc(scene)
+
+
+class MLD(nn.Module):
+
+    def __init__(self, cfg, datamodule=None, smpl_model: Optional[nn.Module] = None, **kwargs):
+        super().__init__()
+        self.cfg = cfg
+        self.stage = cfg.TRAIN.STAGE
+        self.condition = cfg.model.condition
+        self.is_vae = cfg.model.vae
+        self.predict_epsilon = cfg.TRAIN.ABLATION.PREDICT_EPSILON
+        self.name_dataset = cfg.DATASET_NAME
+        self.latent_dim = cfg.model.latent_dim
+        self.guidance_scale = cfg.model.guidance_scale
+        self.guidance_uncodp = cfg.model.guidance_uncondp
+        self.datamodule = datamodule
+        self.estimate = cfg.ESTIMATE
+        self.predict_transl = cfg.TRAIN.ABLATION.PREDICT_TRANSL
+        self.data_type = cfg.DATA_TYPE
+        self.see_future = cfg.TEST.get("SEE_FUTURE", False)
+        if self.name_dataset == "egobody":                               # mld.py:122-125
+            self.nfeats = 75 if self.predict_transl else 72
+        elif self.name_dataset == "gimo":
+            self.nfeats = 69 if self.predict_transl else 66
+        else:
+            self.nfeats = cfg.model.nfeats
+        if "image" in self.condition:
+            raise NotImplementedError("image conditioning (ProHMR ResNet-50 backbone) is outside the accelerated path")
+
+        # SMPL (mld.py:151-153); frozen
+        if smpl_model is not None:
+            self.smpl_model = smpl_model
+        else:
+            self.smpl_model = SMPL(model_path=cfg.model.smpl_path, batch_size=cfg.TRAIN.BATCH_SIZE, gender="neutral")
+        for p in self.smpl_model.parameters():
+            p.requires_grad = False
+
+        self.vae_type = cfg.model.get("vae_type", None) or \
+            cfg.model.motion_vae.target.split(".")[-1].lower().replace("vae", "")      # mld.py:174-179
+        if "scene" in self.condition:                                     # mld.py:182-207, 257-261
+            self.proscene = _SceneEncoderHolder()
+            for p in self.proscene.parameters():
+                p.requires_grad = False
+            self.output_scene = nn.Sequential(nn.ReLU(), nn.Linear(512, 256))
+        self.vae = instantiate_from_config(cfg.model.motion_vae)          # :264
+        if self.stage == "diffusion":                                     # :267-271
+            for p in self.vae.parameters():
+                p.requires_grad = False
+        self.denoiser = instantiate_from_config(cfg.model.denoiser)       # :282
+        if not self.predict_epsilon:
+            cfg.model.scheduler.params["prediction_type"] = "sample"
+            cfg.model.noise_scheduler.params["prediction_type"] = "sample"
+        self.scheduler = instantiate_from_config(cfg.model.scheduler)     # :286-287
+        self.noise_scheduler = instantiate_from_config(cfg.model.noise_scheduler)
+        if cfg.TRAIN.OPTIM.TYPE.lower() != "adamw":
+            raise NotImplementedError("Do not support other optimizer for now.")
+        self.optimizer = None          # built lazily: parameters must be on the device first
+        self.losses = {k: MLDLosses(cfg) for k in ("train", "val", "test")}
+        self.EgoMetric = EgoMetrics()
+        self.do_classifier_free_guidance = self.guidance_scale > 1.0
+        self.renorm = datamodule.renorm if datamodule is not None else (lambda x: x)
+        self.times: List[float] = []
+
+    # ------------------------------------------------------------------ optimiser (mld.py:292-299, base.py:157-158)
+    def configure_optimizers(self):
+        if self.optimizer is None:
+            params = [p for p in self.parameters() if p.requires_grad]
+            self.optimizer = torch.optim.AdamW(params, lr=self.cfg.TRAIN.OPTIM.LR)
+            self.sch = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=self.cfg.TRAIN.OPTIM.STEP_SIZE,
+                                                       gamma=self.cfg.TRAIN.OPTIM.GAMMA)
+        return {"optimizer": self.optimizer}
+
+    def trainable_parameters(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    # ------------------------------------------------------------------ condition assembly
+    def _scene_token(self, scene, cfg_mask_train=False):
+        scene = scene.float()
+        if cfg_mask_train and self.do_classifier_free_guidance:           # mld.py:917-919
+            mask = torch.rand_like(scene) < self.guidance_uncodp
+            scene = torch.where(mask, torch.zeros_like(scene), scene)
+        s512 = self.proscene.encode_scene(scene)                          # HIP PointNet
+        # output_scene = ReLU + Linear(512,256) (trainable, mld.py:257-261): torch op so that autograd sees it
+        return self.output_scene(s512).unsqueeze(0)                       # [1,B,256]
+
+    def _wearer_features(self, feats_ref, transl, idx):
+        f = feats_ref[:, :, idx, :]
+        if self.predict_transl:
+            f = torch.cat([f, transl[:, idx, :, :]], dim=-1)
+        return f[..., : self.nfeats].contiguous() if f.shape[-1] > self.nfeats else f.contiguous()
+
+    # ------------------------------------------------------------------ reverse diffusion (mld.py:432-511)
+    def _diffusion_reverse(self, encoder_hidden_states, lengths=None, latents=None, step_noise=None):
+        bsz = encoder_hidden_states.shape[0]
+        if self.do_classifier_free_guidance:
+            bsz = bsz // 2
+        if latents is None:
+            latents = torch.randn((bsz, self.latent_dim[0], self.latent_dim[-1]), device=encoder_hidden_states.device,
+                                  dtype=torch.float)
+        latents = latents * self.scheduler.init_noise_sigma
+        self.scheduler.set_timesteps(self.cfg.model.scheduler.num_inference_timesteps)
+        eta = 0.0
+        if "eta" in set(inspect.signature(self.scheduler.step).parameters.keys()):
+            eta = self.cfg.model.scheduler.eta
+        # the 50 (or 1000) sequential denoiser calls + CFG + scheduler.step are ONE kernel launch
+        return self.denoiser.sample_loop(latents, encoder_hidden_states.contiguous(), self.scheduler, eta=eta,
+                                         guidance_scale=self.guidance_scale if self.do_classifier_free_guidance else 1.0,
+                                         step_noise=step_noise)            # [1,B,256]
+
+    # ------------------------------------------------------------------ forward diffusion (mld.py:582-631)
+    def _diffusion_process(self, latents, encoder_hidden_states, lengths=None, noise=None, timesteps=None):
+        latents = latents.permute(1, 0, 2)
+        if noise is None:
+            noise = torch.randn_like(latents)
+        bsz = latents.shape[0]
+        if timesteps is None:
+            timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (bsz,), device=latents.device)
+        timesteps = timesteps.long()
+        noisy = self.noise_scheduler.add_noise(latents.clone(), noise, timesteps)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.denoiser.parameters()):
+            noise_pred = denoiser_forward_torch(self.denoiser, noisy, timesteps, encoder_hidden_states)  # autograd
+        else:
+            noise_pred = self.denoiser(sample=noisy, timestep=timesteps, encoder_hidden_states=encoder_hidden_states,
+                                       lengths=lengths)[0]                                              # HIP
+        n_set = {"noise": noise, "noise_prior": 0, "noise_pred": noise_pred, "noise_pred_prior": 0}
+        if not self.predict_epsilon:
+            n_set["pred"] = noise_pred
+            n_set["latent"] = latents
+        return n_set
+
+    # ------------------------------------------------------------------ stage-2 training forward (mld.py:887-1017)
+    def train_diffusion_forward(self, batch, noise=None, timesteps=None):
+        if "scene" in self.condition:
+            feats_ref, transl, beta, utils_, scene, length = batch[:6]
+            scene = self._scene_token(scene, cfg_mask_train=True)
+        else:
+            feats_ref, transl, beta, utils_, length = batch[:5]
+            scene = None
+        feats_ref, transl = feats_ref.float(), transl.float()
+        lengths = [feats_ref.shape[1]] * feats_ref.shape[0]
+        with torch.no_grad():
+            idx = 0 if self.estimate == "wearer" else 1
+            z, _ = self.vae.encode(self._wearer_features(feats_ref, transl, idx), None, lengths)
+            z_cond = None
+            if "interactee" in self.condition:
+                f_int = self._wearer_features(feats_ref, transl, 1)
+                if self.do_classifier_free_guidance:                       # mld.py:966-981
+                    mask = torch.rand_like(f_int) < self.guidance_uncodp
+                    f_int = torch.where(mask, torch.zeros_like(f_int), f_int)
+                z_cond, _ = self.vae.encode(f_int, None, lengths)
+        if scene is not None and z_cond is not None:
+            cond_emb = torch.cat([z_cond, scene], dim=0)                    # :991-993
+        elif scene is not None:
+            cond_emb = scene
+        elif z_cond is not None:
+            cond_emb = z_cond
+        else:
+            raise ValueError("no condition: MldDenoiser needs at least one condition token")
+        return {**self._diffusion_process(z, cond_emb, lengths, noise=noise, timesteps=timesteps)}
+
+    # ------------------------------------------------------------------ stage-1 forward (mld.py:633-885), no grad
+    def train_vae_forward(self, batch):
+        feats_ref, transl, beta = batch[0].float(), batch[1].float(), batch[2].float()
+        lengths = [feats_ref.shape[1]] * feats_ref.shape[0]
+        idx = 0 if self.estimate == "wearer" else 1
+        f_ref = self._wearer_features(feats_ref, transl, idx)
+        z, dist_m = self.vae.encode(f_ref, None, lengths)
+        feats_rst = self.vae.decode(z, lengths)
+        joints_ref = self._feats_to_joints(self.renorm(f_ref), beta[:, idx])
+        joints_rst = self._feats_to_joints(self.renorm(feats_rst), beta[:, idx])
+        dist_ref = torch.distributions.Normal(torch.zeros_like(dist_m.loc), torch.ones_like(dist_m.scale))
+        return {"m_ref": f_ref, "m_rst": feats_rst, "joints_ref": joints_ref, "joints_rst": joints_rst,
+                "dist_m": dist_m, "dist_ref": dist_ref, "lat_m": z.permute(1, 0, 2)}
+
+    # ------------------------------------------------------------------ features -> SMPL joints
+    def _feats_to_joints(self, feats, betas, want_vertices=False):
+        """feats [B,T,F] (renormed).  'angle': [global_orient 3 | body_pose 21..23 joints | transl 3];
+        'rot6d': 24 x 6.  Returns joints [B,T,24,3] (and vertices)."""
+        B, T, F = feats.shape
+        if self.data_type == "rot6d":                                      # mld.py:1410-1449
+            R = G.rot6d_to_rotmat(feats[..., :144].reshape(-1, 6)).reshape(B * T, 24, 3, 3)
+            out = self.smpl_model(betas=betas.reshape(-1, 10).float(), body_pose=R[:, 1:], global_orient=R[:, 0:1],
+                                  pose2rot=False, return_verts=want_vertices, transl=None)
+        else:
+            nb = 69 if self.name_dataset == "egobody" else 63
+            body = feats[:, :, 3:3 + nb].reshape(-1, nb).float()
+            if nb < 69:                                                    # GIMO pads 21 -> 23 joints (mld.py:807-813)
+                body = torch.cat([body, torch.zeros(body.shape[0], 69 - nb, device=body.device)], dim=1)
+            go = feats[:, :, :3].reshape(-1, 3).float()
+            tr = feats[:, :, -3:].reshape(-1, 3).float().contiguous() if self.predict_transl else None
+            out = self.smpl_model(betas=betas.reshape(-1, 10).float(), body_pose=body.contiguous(),
+                                  global_orient=go.contiguous(), transl=tr, pose2rot=True, return_verts=want_vertices)
+        joints = out.joints.reshape(B, T, 45, 3)[:, :, :24]                # mld.py:771-773
+        if want_vertices:
+            return joints, out.vertices.reshape(B, T, -1, 3)
+        return joints
+
+    # ------------------------------------------------------------------ evaluation (mld.py:1076-1905, live part)
+    @torch.no_grad()
+    def ego_eval(self, batch, latents=None, want_vertices=False):
+        if "scene" in self.condition:
+            feats_ref, transl, beta, utils_, scene, length = batch[:6]
+            scene_tok = self._scene_token(scene)
+            if self.do_classifier_free_guidance:                           # zero-scene uncond branch (:1144-1158)
+                scene_tok = torch.cat([self._scene_token(torch.zeros_like(scene)), scene_tok], dim=1)
+        else:
+            feats_ref, transl, beta, utils_, length = batch[:5]
+            scene_tok = None
+        feats_ref, transl, beta = feats_ref.float(), transl.float(), beta.float()
+        lengths = length.long().reshape(-1).tolist()
+        start = time.time()
+        text_emb = None
+        if "interactee" in self.condition:                                 # :1271-1295
+            f_int = self._wearer_features(feats_ref, transl, 1)
+            text_emb = self.vae.encode_dist(f_int, lengths)[0:1]
+            # NOTE the reference takes vae.encode(...)[0], the *sampled* latent; `sample_mean` keeps eval deterministic
+            if not getattr(self, "sample_mean", True):
+                text_emb, _ = self.vae.encode(f_int, None, lengths)
+            if self.do_classifier_free_guidance:
+                unc = self.vae.encode_dist(torch.zeros_like(f_int), lengths)[0:1]
+                text_emb = torch.cat([unc, text_emb], dim=1)
+        toks = [t for t in (text_emb, scene_tok) if t is not None]
+        if not toks:
+            raise ValueError("no condition tokens")
+        cond_emb = torch.cat(toks, dim=0)                                   # [N, B or 2B, 256]
+        z = self._diffusion_reverse(cond_emb.permute(1, 0, 2), lengths, latents=latents)
+        if self.see_future:
+            lengths = [int(i // 2) for i in lengths]
+        feats_rst = self.vae.decode(z, lengths)
+        self.times.append(time.time() - start)                              # mld.py:1367-1368
+        idx_ref = 0 if self.estimate == "wearer" else 1
+        min_len = min(feats_ref.shape[1], feats_rst.shape[1])
+        f_ref = self._wearer_features(feats_ref[:, :min_len], transl[:, :, :min_len], idx_ref)
+        f_ref, f_rst = self.renorm(f_ref), self.renorm(feats_rst[:, :min_len].contiguous())
+        b_ref = beta[:, idx_ref, :min_len]
+        out_ref = self._feats_to_joints(f_ref, b_ref, want_vertices)
+        out_rst = self._feats_to_joints(f_rst, b_ref, want_vertices)
+        joints_ref, joints_rst = (out_ref[0], out_rst[0]) if want_vertices else (out_ref, out_rst)
+        f_int_r = self.renorm(self._wearer_features(feats_ref[:, :min_len], transl[:, :, :min_len], 1))
+        joints_int = self._feats_to_joints(f_int_r, beta[:, 1, :min_len])
+        quat = (lambda f: G.aa_to_quat(f[:, :, :3].reshape(-1, 3).contiguous())) if self.data_type == "angle" else (lambda f: None)
+        rs = {"m_ref": f_ref, "m_rst": f_rst, "joints_ref": joints_ref, "joints_rst": joints_rst,
+              "orientation_quat_rst": quat(f_rst), "orientation_quat_ref": quat(f_ref),
+              "root_interactee": joints_int[:, :, 0], "joints_interactee": joints_int,
+              "orientation_quat_int": quat(f_int_r), "joints_interactee_gt": None, "lengths": lengths,
+              "list_names": {}, "lat_t": z}
+        if want_vertices:
+            rs["vertices_ref"], rs["vertices_rst"] = out_ref[1], out_rst[1]
+        return rs
+
+    def forward(self, batch, **kw):
+        return self.ego_eval(batch, **kw)
+
+    sample = forward
+
+    # ------------------------------------------------------------------ step dispatch (mld.py:2037-2130, base.py:38-53)
+    def allsplit_step(self, split: str, batch, batch_idx=0):
+        loss = None
+        if split in ("train", "val"):
+            if self.stage == "vae":
+                rs_set = self.train_vae_forward(batch)
+            elif self.stage == "diffusion":
+                rs_set = self.train_diffusion_forward(batch)
+            else:
+                raise ValueError(f"Not support this stage {self.stage}!")
+            loss = self.losses[split].update(rs_set)
+        if split in ("val", "test"):
+            rs_set = self.ego_eval(batch)
+            self.EgoMetric.update(rs_set["joints_rst"], rs_set["joints_ref"], rs_set["lengths"])
+        if split == "test":
+            return rs_set["joints_rst"]
+        return loss
+
+    def training_step(self, batch, batch_idx=0):
+        return self.allsplit_step("train", batch, batch_idx)
+
+    def validation_step(self, batch, batch_idx=0):
+        return self.allsplit_step("val", batch, batch_idx)
+
+    def test_step(self, batch, batch_idx=0):
+        return self.allsplit_step("test", batch, batch_idx)
+
+    def optimizer_step(self, loss, world=None):
+        """backward -> (data-parallel) gradient all-reduce -> AdamW step; what Lightning + DDP do around
+        training_step in the reference (train.py:127-149)."""
+        from . import distributed as D
+        self.configure_optimizers()
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        D.allreduce_gradients(self.trainable_parameters())
+        self.optimizer.step()

@@ -1,0 +1,72 @@
+"""world_size-2 gloo tests of the N>1 plumbing (no GPU): sharding of independent sequences, the flat
+gradient all-reduce of the training path and the metric-sum reduction."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, ws, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank))
+    from seeme_amd import distributed as D
+    r, w, _ = D.init_from_env("gloo")
+    assert (r, w) == (rank, ws)
+    # 1) shards of 37 sequences: disjoint, contiguous, cover everything, balanced
+    lo, hi = D.shard_range(37)
+    all_ranges = [None] * ws
+    dist.all_gather_object(all_ranges, (lo, hi))
+    # 2) gradient all-reduce: rank-dependent grads; one parameter without grad
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(8, 4)
+    extra = torch.nn.Parameter(torch.zeros(5))           # never receives a gradient (like mem_pos.pe)
+    params = list(lin.parameters()) + [extra]
+    D.broadcast_parameters(lin)
+    x = torch.full((3, 8), float(rank + 1))
+    lin(x).sum().backward()
+    n = D.allreduce_gradients(params)
+    # 3) metric sums
+    s = D.reduce_sums(torch.tensor([1.0 + rank, 10.0, 1.0], dtype=torch.float64))
+    q.put((rank, all_ranges, n, lin.weight.grad.clone(), extra.grad.clone(), s))
+    dist.destroy_process_group()
+
+
+def test_world2_gloo():
+    ws, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, ws, port, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(ws)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ranges = res[0][1]
+    assert ranges[0][0] == 0 and ranges[-1][1] == 37
+    assert all(ranges[i][1] == ranges[i + 1][0] for i in range(ws - 1))
+    assert max(b - a for a, b in ranges) - min(b - a for a, b in ranges) <= 1
+    # mean of per-rank grads: d/dW sum(Wx+b) = x summed over rows -> 3*(rank+1); mean over ranks = 4.5
+    for r in res:
+        assert r[2] == 8 * 4 + 4 + 5
+        assert torch.allclose(r[3], torch.full((4, 8), 4.5))
+        assert torch.equal(r[4], torch.zeros(5))
+        assert torch.allclose(r[5], torch.tensor([3.0, 20.0, 2.0], dtype=torch.float64))
+
+
+def test_single_process_is_identity():
+    from seeme_amd import distributed as D
+    assert D.world() == (0, 1)
+    assert D.shard_range(10) == (0, 10)
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.ones(3) * 2
+    D.allreduce_gradients([p])
+    assert torch.equal(p.grad, torch.ones(3) * 2)

@@ -120,3 +120,39 @@ def test_timestep_features_match_oracle():
     from seeme_amd.mld_denoiser import timestep_features
     t = torch.tensor([0, 1, 21, 501, 981, 999])
     assert rel_err(timestep_features(t).numpy(), O.timestep_features(t.numpy())) < 1e-4
+
+
+def test_config_loader_own_and_reference_yaml():
+    from seeme_amd.config import parse_config, instantiate_from_config
+    cfg = parse_config(os.path.join(REPO, "configs", "config_mld_scene.yaml"))
+    assert cfg.model.condition == ["text", "scene", "interactee"]
+    assert cfg.model.denoiser.params.ablation.MD_TRANS is True
+    assert cfg.model.denoiser.params.latent_dim == [1, 256]
+    assert isinstance(cfg.TRAIN.OPTIM.LR, float)
+    den = instantiate_from_config(cfg.model.denoiser)
+    sch = instantiate_from_config(cfg.model.scheduler)
+    assert type(den).__name__ == "MldDenoiser" and type(sch).__name__ == "DDIMScheduler"
+    ref = "/root/reference/configs/config_mld_egobody.yaml"       # only in the build container
+    if os.path.exists(ref):
+        r = parse_config(ref)
+        assert r.model.denoiser.target == "mld.models.architectures.mld_denoiser.MldDenoiser"   # file untouched
+        assert type(instantiate_from_config(r.model.denoiser)).__module__ == "seeme_amd.mld_denoiser"
+        assert type(instantiate_from_config(r.model.motion_vae)).__module__ == "seeme_amd.mld_vae"
+        assert type(instantiate_from_config(r.model.scheduler)).__module__ == "seeme_amd.schedulers"
+        assert r.model.scheduler.num_inference_timesteps == 50
+
+
+def test_mld_constructs_from_config_on_cpu():
+    from seeme_amd.config import parse_config
+    from seeme_amd.mld import MLD, SyntheticEgoDataModule
+    from seeme_amd.smpl import SMPL
+    cfg = parse_config(os.path.join(REPO, "configs", "config_mld_scene.yaml"))
+    m = MLD(cfg, SyntheticEgoDataModule(), smpl_model=SMPL.synthetic(1, V=64))
+    keys = set(m.state_dict().keys())
+    assert "vae.encoder.input_blocks.0.self_attn.in_proj_weight" in keys
+    assert "denoiser.encoder.middle_block.sa_block.linear1.weight" in keys
+    assert "proscene.scene_enc.block_3.shortcut.weight" in keys and "output_scene.1.weight" in keys
+    assert "smpl_model.lbs_weights" in keys
+    for name in ("training_step", "validation_step", "test_step", "allsplit_step", "_diffusion_reverse",
+                 "_diffusion_process", "train_vae_forward", "train_diffusion_forward", "ego_eval", "configure_optimizers"):
+        assert callable(getattr(m, name))
