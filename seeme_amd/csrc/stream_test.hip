@@ -57,6 +57,58 @@ __global__ __launch_bounds__(512) void k_stream_regs(const float4* __restrict__ 
     out[(size_t)blockIdx.x * blockDim.x + tid] = (acc.x + acc.y) + (acc.z + acc.w);
 }
 
+// mode 2: the GEMV pattern of the sampling kernel -- double-buffered chunks of CH x 16 B per lane through raw
+// buffer loads, a workgroup barrier + a short wave-local epilogue every `per_gemv` chunks.
+template <int CH>
+__global__ __launch_bounds__(512) void k_stream_gemv(const float4* __restrict__ src, int bytes, long npw, int reps,
+                                                     int per_gemv, int epi_iters, float* __restrict__ out) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ float red[512];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(src), 0, bytes, 0x00020000);
+    const unsigned voff = (unsigned)(wave * 64 + lane) * 16u;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long nchunks = npw * reps / CH;
+    u32x4 A[CH], B[CH];
+    auto soff = [&](long c, int i) { return (unsigned)((((c * CH + i) % npw) * 8) * 1024); };
+#pragma unroll
+    for (int i = 0; i < CH; ++i) A[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff(0, i), 0);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) B[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff(1, i), 0);
+    for (long c = 0; c + 1 < nchunks; c += 2) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { acc.x += __uint_as_float(A[i].x); acc.y += __uint_as_float(A[i].y); acc.z += __uint_as_float(A[i].z); acc.w += __uint_as_float(A[i].w); }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) A[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff(c + 2, i), 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { acc.x += __uint_as_float(B[i].x); acc.y += __uint_as_float(B[i].y); acc.z += __uint_as_float(B[i].z); acc.w += __uint_as_float(B[i].w); }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) B[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff(c + 3, i), 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (per_gemv > 0 && ((c + 2) % per_gemv) == 0) {
+            red[tid] = acc.x;
+            __syncthreads();
+            float v = red[(tid + 64) & 511];
+            for (int e = 0; e < epi_iters; ++e) v = wave_sum(v) * 0.015625f + 1e-9f;
+            acc.w += v * 1e-30f;
+        }
+    }
+    out[(size_t)blockIdx.x * blockDim.x + tid] = (acc.x + acc.y) + (acc.z + acc.w);
+    asm volatile("" ::"v"(A[0].x), "v"(B[0].x));
+}
+
+extern "C" int seeme_debug_stream_gemv(const float* src, long bytes, int reps, int ch, int per_gemv, int epi_iters,
+                                       int blocks, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const long npw = bytes / 1024 / 8;
+    if (ch == 8) hipLaunchKernelGGL((k_stream_gemv<8>), dim3(blocks), dim3(512), 0, st, (const float4*)src, (int)bytes, npw, reps, per_gemv, epi_iters, out);
+    else if (ch == 4) hipLaunchKernelGGL((k_stream_gemv<4>), dim3(blocks), dim3(512), 0, st, (const float4*)src, (int)bytes, npw, reps, per_gemv, epi_iters, out);
+    else if (ch == 16) hipLaunchKernelGGL((k_stream_gemv<16>), dim3(blocks), dim3(512), 0, st, (const float4*)src, (int)bytes, npw, reps, per_gemv, epi_iters, out);
+    else return seeme_fail("debug_stream_gemv: ch must be 4, 8 or 16");
+    return seeme_check_launch("k_stream_gemv");
+}
+
 extern "C" int seeme_debug_stream(const float* src, long bytes, int reps, int mode, int ring, int blocks, float* out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int NW = 8;
