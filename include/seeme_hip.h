@@ -89,6 +89,10 @@ typedef struct {
     const float* fin_w;         /* final_layer.weight [F,256] */
     const float* fin_b;
     SeemeSkipStack enc, dec;
+    /* decoder cross-attention to the single latent token, folded on the host:
+     * c_l = ca_fold_w[l*256:(l+1)*256] z + ca_fold_b[...],  ca_fold_w = out_proj_l . W_v_l,  ca_fold_b = out_proj_l b_v_l + b_o_l */
+    const float* ca_fold_w;     /* [5*256, 256] */
+    const float* ca_fold_b;     /* [5*256] */
 } SeemeVaeWeights;
 
 size_t seeme_vae_workspace_bytes(int B, int T);
@@ -127,6 +131,10 @@ typedef struct {
     const float* time_w1; const float* time_b1; const float* time_w2; const float* time_b2;
     const float* ca_kv_w[SEEME_NLAYERS]; const float* ca_kv_b[SEEME_NLAYERS];   /* [512,256] key|value per layer */
     const float* ca_tn_w[SEEME_NLAYERS]; const float* ca_tn_b[SEEME_NLAYERS];   /* ca_block.text_norm */
+    /* key|value of all layers with the text_norm affine folded in: [5*512,256] = W_l diag(tn_w_l),
+     * bias W_l tn_b_l + b_l; applied to the affine-free LayerNorm of the condition (ln_ones / ln_zeros) */
+    const float* ca_fold_w; const float* ca_fold_b;
+    const float* ln_ones; const float* ln_zeros;                                /* [256] each */
 } SeemeDenoiserWeights;
 
 /* per-row time tables: floats per row = 5*512 (sa K|V of the time token) + 5*1024 (AdaLN scale|shift, ca|ffn) */

@@ -47,7 +47,7 @@ class SkipStack(C.Structure):
 class VaeWeights(C.Structure):
     _fields_ = [("nfeats", C.c_int), ("ff", C.c_int), ("token", fp), ("pe_enc", fp), ("pe_dec", fp),
                 ("emb_w", fp), ("emb_ldw", C.c_int), ("emb_b", fp), ("fin_w", fp), ("fin_b", fp),
-                ("enc", SkipStack), ("dec", SkipStack)]
+                ("enc", SkipStack), ("dec", SkipStack), ("ca_fold_w", fp), ("ca_fold_b", fp)]
 
 
 class DenoiserWeights(C.Structure):
@@ -55,7 +55,8 @@ class DenoiserWeights(C.Structure):
                 ("ff", C.c_int), ("kv_cat_w", fp), ("kv_cat_b", fp), ("style_cat_w", fp), ("style_cat_b", fp),
                 ("time_w1", fp), ("time_b1", fp), ("time_w2", fp), ("time_b2", fp),
                 ("ca_kv_w", fp * NLAYERS), ("ca_kv_b", fp * NLAYERS),
-                ("ca_tn_w", fp * NLAYERS), ("ca_tn_b", fp * NLAYERS)]
+                ("ca_tn_w", fp * NLAYERS), ("ca_tn_b", fp * NLAYERS),
+                ("ca_fold_w", fp), ("ca_fold_b", fp), ("ln_ones", fp), ("ln_zeros", fp)]
 
 
 class SampleArgs(C.Structure):

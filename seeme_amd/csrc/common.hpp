@@ -70,12 +70,20 @@ __device__ __forceinline__ void tile_gemm_f32(const float* __restrict__ As, int 
         wp[nt] = W + (size_t)n * ldw + 4 * kq;
     }
     const float* ap = As + r * lda + 4 * kq;
+    // software pipeline: the weight fragments of k-block kb+1 are requested before the MFMAs of block kb
+    // (the k-loop is otherwise bound by one L2 round trip per 16 k)
+    float4 bn[NTL];
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) bn[nt] = *reinterpret_cast<const float4*>(wp[nt]);
     for (int kb = 0; kb < K16; ++kb) {
         float4 a[MTL], b[NTL];
 #pragma unroll
-        for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
+        for (int nt = 0; nt < NTL; ++nt) b[nt] = bn[nt];
+        const int kn = (kb + 1 < K16) ? kb + 1 : kb;
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt) b[nt] = *reinterpret_cast<const float4*>(wp[nt] + kb * 16);
+        for (int nt = 0; nt < NTL; ++nt) bn[nt] = *reinterpret_cast<const float4*>(wp[nt] + kn * 16);
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
 #pragma unroll
         for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
@@ -98,19 +106,28 @@ __device__ __forceinline__ void tile_gemm_f32_kn(const float* __restrict__ As, i
     const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
     const float* ap = As + r * lda + 4 * kq;
     const float* vp = V + n0 + r;
-    for (int kb = 0; kb < K16; ++kb) {
-        float4 a[MTL];
-        float b[NTL][4];
-#pragma unroll
-        for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
+    float bn[NTL][4];
+    auto fetch = [&](int kb, float (&dst)[NTL][4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int k = kb * 16 + 4 * kq + j;
             k = k < k_valid ? k : k_valid - 1;
             const float* row = vp + (size_t)k * ldv;
 #pragma unroll
-            for (int nt = 0; nt < NTL; ++nt) b[nt][j] = row[nt * 16];
+            for (int nt = 0; nt < NTL; ++nt) dst[nt][j] = row[nt * 16];
         }
+    };
+    fetch(0, bn);
+    for (int kb = 0; kb < K16; ++kb) {
+        float4 a[MTL];
+        float b[NTL][4];
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[nt][j] = bn[nt][j];
+        fetch((kb + 1 < K16) ? kb + 1 : kb, bn);
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
 #pragma unroll
         for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll

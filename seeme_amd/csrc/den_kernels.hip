@@ -627,9 +627,11 @@ extern "C" int seeme_denoiser_cond_tables(const SeemeDenoiserWeights* w, const f
     int rc;
     // sa_block K|V of the condition tokens, all layers at once
     if ((rc = seeme_linear_simple(st, cond, 256, w->kv_cat_w, 256, w->kv_cat_b, ctab, SEEME_CROW, M, 2560, 256, 0, 0, nullptr, nullptr))) return rc;
-    // ca_block: key|value of text_norm(xf) per layer (mdiff_transformer.py:230,234); the token softmax is applied in-kernel
-    for (int l = 0; l < SEEME_NLAYERS; ++l)
-        if ((rc = seeme_linear_simple(st, cond, 256, w->ca_kv_w[l], 256, w->ca_kv_b[l], ctab + 2560 + l * 512, SEEME_CROW,
-                                      M, 512, 256, 0, 0, w->ca_tn_w[l], w->ca_tn_b[l]))) return rc;
+    // ca_block: key|value of text_norm(xf) for all layers in one GEMM -- the per-layer LayerNorm affine is
+    // folded into the weights, so the input is the affine-free LayerNorm of the condition
+    // (mdiff_transformer.py:230,234); the token softmax of the keys is applied in-kernel
+    if (w->ca_fold_w == nullptr) return seeme_fail("cond_tables: folded key/value weights missing");
+    if ((rc = seeme_linear_simple(st, cond, 256, w->ca_fold_w, 256, w->ca_fold_b, ctab + 2560, SEEME_CROW, M, 2560, 256, 0, 0,
+                                  w->ln_ones, w->ln_zeros))) return rc;
     return 0;
 }

@@ -24,16 +24,32 @@ __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
     const int cn0 = blockIdx.y * CH_N;
 
     // ---- stage A tile (zero padded), optional pre-LN and pre-activation
-    for (int idx = tid; idx < TILE_M * Kp; idx += 256) {
-        const int row = idx / Kp, c = idx - row * Kp;
-        const int m = m0 + row;
-        float v = 0.f;
-        if (m < a.M && c < a.K) {
-            int prow = m;
-            if (ka.seq_in > 0) prow = (m / ka.seq_in) * ka.in_stride + (m % ka.seq_in) + ka.in_off;
-            v = (c < a.K1) ? a.A[(size_t)prow * a.lda + c] : a.A2[(size_t)prow * a.lda2 + (c - a.K1)];
+    const bool a_vec = (a.A2 == nullptr) && ((a.K & 3) == 0) && ((a.lda & 3) == 0) && ((reinterpret_cast<size_t>(a.A) & 15) == 0);
+    if (a_vec) {   // float4 path: K/4 vectors per row, rows spread over the 256 threads
+        const int K4 = a.K >> 2, Kp4 = Kp >> 2;
+        for (int idx = tid; idx < TILE_M * Kp4; idx += 256) {
+            const int row = idx / Kp4, c4 = idx - row * Kp4;
+            const int m = m0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < a.M && c4 < K4) {
+                int prow = m;
+                if (ka.seq_in > 0) prow = (m / ka.seq_in) * ka.in_stride + (m % ka.seq_in) + ka.in_off;
+                v = *reinterpret_cast<const float4*>(a.A + (size_t)prow * a.lda + 4 * c4);
+            }
+            *reinterpret_cast<float4*>(As + row * lda_s + 4 * c4) = v;
         }
-        As[row * lda_s + c] = v;
+    } else {
+        for (int idx = tid; idx < TILE_M * Kp; idx += 256) {
+            const int row = idx / Kp, c = idx - row * Kp;
+            const int m = m0 + row;
+            float v = 0.f;
+            if (m < a.M && c < a.K) {
+                int prow = m;
+                if (ka.seq_in > 0) prow = (m / ka.seq_in) * ka.in_stride + (m % ka.seq_in) + ka.in_off;
+                v = (c < a.K1) ? a.A[(size_t)prow * a.lda + c] : a.A2[(size_t)prow * a.lda2 + (c - a.K1)];
+            }
+            As[row * lda_s + c] = v;
+        }
     }
     __syncthreads();
     if (a.pre_ln_w != nullptr) {  // LayerNorm over K (any K), one wave per 8 rows
@@ -261,7 +277,8 @@ struct FfnKArgs {
     const float* x; float* out;     // [rows][256]
     const float* w1; const float* b1; const float* w2; const float* b2;
     const float* ln_w; const float* ln_b;
-    const float* cvec;              // optional [B][256] cross-attention vector
+    const float* cvec;              // optional cross-attention vector per sequence, row stride cvec_ld
+    int cvec_ld;
     const float* lnc_w; const float* lnc_b;
     const float* fin_w; const float* fin_b;   // optional extra LayerNorm after the block (stack norm)
     int M;            // logical rows
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(256) void k_ffn_block(const FfnKArgs a) {
             const size_t prow = (size_t)seq * a.seq_stride + (m % a.seq_rows);
             v = *reinterpret_cast<const float4*>(a.x + prow * 256 + lane * 4);
             if (a.cvec != nullptr) {
-                const float4 c = *reinterpret_cast<const float4*>(a.cvec + (size_t)seq * 256 + lane * 4);
+                const float4 c = *reinterpret_cast<const float4*>(a.cvec + (size_t)seq * a.cvec_ld + lane * 4);
                 v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
                 v = wave_layernorm256(v, a.lnc_w, a.lnc_b, a.eps);
             }
@@ -391,7 +408,7 @@ static VaeWs carve(void* ws, int B, int S) {
 //   cur (in) -> out;  decoder layers additionally take the per-sequence cross vector.
 static int run_layer(hipStream_t st, const SeemeXfLayer& L, int ff, int act, float* cur, float* mid, float* out,
                      float* qkv, const int32_t* lengths, int B, int S, int n_prefix, int q_rows,
-                     const float* cvec, const float* fin_w, const float* fin_b, int out_mode) {
+                     const float* cvec, const float* fin_w, const float* fin_b, int out_mode, int cvec_ld = 256) {
     int rc = linear_simple(st, cur, 256, L.in_w, 256, L.in_b, qkv, 768, B * S, 768, 256);
     if (rc) return rc;
     AttnKArgs at{};
@@ -405,7 +422,7 @@ static int run_layer(hipStream_t st, const SeemeXfLayer& L, int ff, int act, flo
     f.M = B * q_rows; f.FF = ff; f.act = act; f.seq_rows = q_rows; f.seq_stride = S; f.out_mode = out_mode;
     f.eps = 1e-5f; f.fin_w = fin_w; f.fin_b = fin_b;
     if (cvec != nullptr) {
-        f.cvec = cvec; f.lnc_w = L.n2_w; f.lnc_b = L.n2_b; f.ln_w = L.n3_w; f.ln_b = L.n3_b;
+        f.cvec = cvec; f.cvec_ld = cvec_ld; f.lnc_w = L.n2_w; f.lnc_b = L.n2_b; f.ln_w = L.n3_w; f.ln_b = L.n3_b;
     } else {
         f.ln_w = L.n2_w; f.ln_b = L.n2_b;
     }
@@ -467,26 +484,23 @@ extern "C" int seeme_vae_decode(const SeemeVaeWeights* w, const float* z, const 
     int rc;
     // cross-attention to the single memory token: softmax over one key == 1, so the block adds
     // c_l[b] = out_proj(W_v z_b + b_v) to every query (cross_attention.py:358-361)
-    for (int l = 0; l < SEEME_NLAYERS; ++l) {
-        const SeemeXfLayer& L = Dk.layer[l];
-        if ((rc = linear_simple(st, z, 256, L.ca_in_w + 512 * 256, 256, L.ca_in_b + 512, ws.tmp, 256, B, 256, 256))) return rc;
-        if ((rc = linear_simple(st, ws.tmp, 256, L.ca_out_w, 256, L.ca_out_b, ws.cvec + (size_t)l * B * 256, 256, B, 256, 256))) return rc;
-    }
+    if (w->ca_fold_w == nullptr) return seeme_fail("vae_decode: folded cross-attention weights missing");
+    const int CL = SEEME_NLAYERS * 256;
+    if ((rc = linear_simple(st, z, 256, w->ca_fold_w, 256, w->ca_fold_b, ws.cvec, CL, B, CL, 256))) return rc;
     {
         const size_t n4 = (size_t)B * S * 64;
         hipLaunchKernelGGL(k_bcast_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w->pe_dec, ws.x, B, S);
         if ((rc = seeme_check_launch("k_bcast_rows"))) return rc;
     }
     const int ff = w->ff, act = SEEME_ACT_GELU;
-    const size_t cs = (size_t)B * 256;
     // SkipTransformerDecoder.forward (cross_attention.py:118-147)
-    if ((rc = run_layer(st, Dk.layer[0], ff, act, ws.x, ws.y, ws.sk0, ws.qkv, lengths, B, S, 0, S, ws.cvec + 0 * cs, nullptr, nullptr, 0))) return rc;
-    if ((rc = run_layer(st, Dk.layer[1], ff, act, ws.sk0, ws.y, ws.sk1, ws.qkv, lengths, B, S, 0, S, ws.cvec + 1 * cs, nullptr, nullptr, 0))) return rc;
-    if ((rc = run_layer(st, Dk.layer[2], ff, act, ws.sk1, ws.y, ws.x, ws.qkv, lengths, B, S, 0, S, ws.cvec + 2 * cs, nullptr, nullptr, 0))) return rc;
+    if ((rc = run_layer(st, Dk.layer[0], ff, act, ws.x, ws.y, ws.sk0, ws.qkv, lengths, B, S, 0, S, ws.cvec + 0 * 256, nullptr, nullptr, 0, CL))) return rc;
+    if ((rc = run_layer(st, Dk.layer[1], ff, act, ws.sk0, ws.y, ws.sk1, ws.qkv, lengths, B, S, 0, S, ws.cvec + 1 * 256, nullptr, nullptr, 0, CL))) return rc;
+    if ((rc = run_layer(st, Dk.layer[2], ff, act, ws.sk1, ws.y, ws.x, ws.qkv, lengths, B, S, 0, S, ws.cvec + 2 * 256, nullptr, nullptr, 0, CL))) return rc;
     if ((rc = skip_linear(st, ws.x, ws.sk1, Dk.skip_w[0], Dk.skip_b[0], ws.x, B * S))) return rc;
-    if ((rc = run_layer(st, Dk.layer[3], ff, act, ws.x, ws.y, ws.x, ws.qkv, lengths, B, S, 0, S, ws.cvec + 3 * cs, nullptr, nullptr, 0))) return rc;
+    if ((rc = run_layer(st, Dk.layer[3], ff, act, ws.x, ws.y, ws.x, ws.qkv, lengths, B, S, 0, S, ws.cvec + 3 * 256, nullptr, nullptr, 0, CL))) return rc;
     if ((rc = skip_linear(st, ws.x, ws.sk0, Dk.skip_w[1], Dk.skip_b[1], ws.x, B * S))) return rc;
-    if ((rc = run_layer(st, Dk.layer[4], ff, act, ws.x, ws.y, ws.x, ws.qkv, lengths, B, S, 0, S, ws.cvec + 4 * cs, nullptr, nullptr, 0))) return rc;
+    if ((rc = run_layer(st, Dk.layer[4], ff, act, ws.x, ws.y, ws.x, ws.qkv, lengths, B, S, 0, S, ws.cvec + 4 * 256, nullptr, nullptr, 0, CL))) return rc;
     // stack norm + final_layer (mld_vae.py:251)
     return linear_simple(st, ws.x, 256, w->fin_w, 256, w->fin_b, feats, F, B * S, F, 256, SEEME_ACT_NONE,
                          SEEME_ACT_NONE, Dk.norm_w, Dk.norm_b);

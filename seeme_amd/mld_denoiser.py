@@ -217,6 +217,10 @@ class MldDenoiser(nn.Module):
                               for b in blocks]).contiguous()
             ca_w = [torch.cat([b.ca_block.key.weight, b.ca_block.value.weight]).contiguous() for b in blocks]
             ca_b = [torch.cat([b.ca_block.key.bias, b.ca_block.value.bias]).contiguous() for b in blocks]
+            # text_norm affine folded into key|value: W diag(g), W beta + b
+            cf_w = torch.cat([ca_w[l] * blk.ca_block.text_norm.weight[None, :] for l, blk in enumerate(blocks)]).contiguous()
+            cf_b = torch.cat([ca_w[l] @ blk.ca_block.text_norm.bias + ca_b[l] for l, blk in enumerate(blocks)]).contiguous()
+            ones, zeros = torch.ones(256, device=dev), torch.zeros(256, device=dev)
         lay_dev = torch.tensor(self._layout_vals, dtype=torch.int64, device=dev)
         w = L.DenoiserWeights()
         w.wg, w.wdtype, w.vp, w.layout = wg.data_ptr(), 1 if bf16 else 0, vp.data_ptr(), lay_dev.data_ptr()
@@ -228,7 +232,8 @@ class MldDenoiser(nn.Module):
         for l, b in enumerate(blocks):
             w.ca_kv_w[l], w.ca_kv_b[l] = ca_w[l].data_ptr(), ca_b[l].data_ptr()
             w.ca_tn_w[l], w.ca_tn_b[l] = L.ptr(b.ca_block.text_norm.weight), L.ptr(b.ca_block.text_norm.bias)
-        self._wcache = (fpnt, w, (wg, vp, kv_w, kv_b, st_w, st_b, ca_w, ca_b, lay_dev))
+        w.ca_fold_w, w.ca_fold_b, w.ln_ones, w.ln_zeros = cf_w.data_ptr(), cf_b.data_ptr(), ones.data_ptr(), zeros.data_ptr()
+        self._wcache = (fpnt, w, (wg, vp, kv_w, kv_b, st_w, st_b, ca_w, ca_b, lay_dev, cf_w, cf_b, ones, zeros))
         self._table_cache = {}
         return w
 

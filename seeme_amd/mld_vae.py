@@ -174,6 +174,17 @@ class MldVae(nn.Module):
                 dst.skip_w[i] = L.ptr(stack.linear_blocks[i].weight)
                 dst.skip_b[i] = L.ptr(stack.linear_blocks[i].bias)
             dst.norm_w, dst.norm_b = L.ptr(stack.norm.weight), L.ptr(stack.norm.bias)
+        with torch.no_grad():   # decoder cross-attention to one memory token, folded
+            D = self.latent_dim
+            fw, fb = [], []
+            for blk in self.decoder.blocks():
+                wv, bv = blk.multihead_attn.in_proj_weight[2 * D:], blk.multihead_attn.in_proj_bias[2 * D:]
+                wo, bo = blk.multihead_attn.out_proj.weight, blk.multihead_attn.out_proj.bias
+                fw.append(wo @ wv)
+                fb.append(wo @ bv + bo)
+            fold_w, fold_b = torch.cat(fw).contiguous(), torch.cat(fb).contiguous()
+        keep += [fold_w, fold_b]
+        w.ca_fold_w, w.ca_fold_b = fold_w.data_ptr(), fold_b.data_ptr()
         self._wcache = (fpnt, w, keep)
         return w
 
