@@ -70,29 +70,49 @@ __device__ __forceinline__ void tile_gemm_f32(const float* __restrict__ As, int 
         wp[nt] = W + (size_t)n * ldw + 4 * kq;
     }
     const float* ap = As + r * lda + 4 * kq;
-    // software pipeline: the weight fragments of k-block kb+1 are requested before the MFMAs of block kb
-    // (the k-loop is otherwise bound by one L2 round trip per 16 k)
-    float4 bn[NTL];
+    // software pipeline, PF k-blocks deep: the weight fragments of block kb+PF are requested before the
+    // MFMAs of block kb (a workgroup tile is otherwise bound by one L2/HBM round trip per 16 k: ~1.3 us)
+    constexpr int PF = 4;
+    float4 br[PF][NTL];
 #pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) bn[nt] = *reinterpret_cast<const float4*>(wp[nt]);
-    for (int kb = 0; kb < K16; ++kb) {
-        float4 a[MTL], b[NTL];
+    for (int u = 0; u < PF; ++u) {
+        const int kk = u < K16 ? u : K16 - 1;
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt) b[nt] = bn[nt];
-        const int kn = (kb + 1 < K16) ? kb + 1 : kb;
+        for (int nt = 0; nt < NTL; ++nt) br[u][nt] = *reinterpret_cast<const float4*>(wp[nt] + kk * 16);
+    }
+    for (int kb0 = 0; kb0 < K16; kb0 += PF) {
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt) bn[nt] = *reinterpret_cast<const float4*>(wp[nt] + kn * 16);
+        for (int u = 0; u < PF; ++u) {
+            const int kb = kb0 + u;
+            if (kb < K16) {
+                float4 a[MTL], b[NTL];
 #pragma unroll
-        for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
+                for (int nt = 0; nt < NTL; ++nt) b[nt] = br[u][nt];
+                const int kn = (kb + PF < K16) ? kb + PF : K16 - 1;
 #pragma unroll
-        for (int mt = 0; mt < MTL; ++mt)
+                for (int nt = 0; nt < NTL; ++nt) br[u][nt] = *reinterpret_cast<const float4*>(wp[nt] + kn * 16);
 #pragma unroll
-            for (int nt = 0; nt < NTL; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+                for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
+                // j outermost: MTL*NTL independent accumulators between two uses of the same one
+                // (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency)
+#pragma unroll
+                for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
             }
+        }
     }
 }
 
@@ -106,7 +126,8 @@ __device__ __forceinline__ void tile_gemm_f32_kn(const float* __restrict__ As, i
     const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
     const float* ap = As + r * lda + 4 * kq;
     const float* vp = V + n0 + r;
-    float bn[NTL][4];
+    constexpr int PF = 3;
+    float br[PF][NTL][4];
     auto fetch = [&](int kb, float (&dst)[NTL][4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -117,26 +138,33 @@ __device__ __forceinline__ void tile_gemm_f32_kn(const float* __restrict__ As, i
             for (int nt = 0; nt < NTL; ++nt) dst[nt][j] = row[nt * 16];
         }
     };
-    fetch(0, bn);
-    for (int kb = 0; kb < K16; ++kb) {
-        float4 a[MTL];
-        float b[NTL][4];
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt)
+    for (int u = 0; u < PF; ++u) fetch(u < K16 ? u : K16 - 1, br[u]);
+    for (int kb0 = 0; kb0 < K16; kb0 += PF) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[nt][j] = bn[nt][j];
-        fetch((kb + 1 < K16) ? kb + 1 : kb, bn);
+        for (int u = 0; u < PF; ++u) {
+            const int kb = kb0 + u;
+            if (kb < K16) {
+                float4 a[MTL];
+                float b[NTL][4];
 #pragma unroll
-        for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
+                for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MTL; ++mt)
+                    for (int j = 0; j < 4; ++j) b[nt][j] = br[u][nt][j];
+                fetch((kb + PF < K16) ? kb + PF : K16 - 1, br[u]);
 #pragma unroll
-            for (int nt = 0; nt < NTL; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt][0], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt][1], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt][2], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt][3], acc[mt][nt], 0, 0, 0);
+                for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
+#pragma unroll
+                for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTL; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt][0], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt][1], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt][2], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt][3], acc[mt][nt], 0, 0, 0);
+                    }
             }
+        }
     }
 }
 

@@ -69,11 +69,17 @@ __device__ __forceinline__ void issue_rt(WBuf& b, __amdgpu_buffer_rsrc_t rsrc, c
 }
 template <int CH>
 __device__ __forceinline__ void issue_n(WBuf& b, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, int stride) {
+#ifdef DEN_DBG_NOLOAD   // timing probe: arithmetic and epilogues without the weight stream
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < CH; ++i) b.r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + (unsigned)(i * stride), 0);
 }
 template <int CH, int STRIDE>
 __device__ __forceinline__ void issue_ct(WBuf& b, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+#ifdef DEN_DBG_NOLOAD
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < CH; ++i) b.r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + (unsigned)(i * STRIDE), 0);
 }
@@ -84,6 +90,11 @@ __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 
 // acc[s] += W-chunk . x[s][k0 ...]   (x in LDS, broadcast reads; packed fp32 FMAs)
 template <typename WT, int CH, int MS>
 __device__ __forceinline__ void consume(const WBuf& b, const float* __restrict__ x, int ldx, int k0, f2 (&acc)[MS][2]) {
+#ifdef DEN_DBG_NOFMA   // timing probe: keep the weight stream, drop the arithmetic (results are garbage)
+#pragma unroll
+    for (int i = 0; i < CH; ++i) acc[0][0].x += __uint_as_float(b.r[i].x ^ b.r[i].y ^ b.r[i].z ^ b.r[i].w);
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         const u32x4 u = b.r[i];

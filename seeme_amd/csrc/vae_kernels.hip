@@ -178,7 +178,15 @@ __global__ __launch_bounds__(256) void k_attn_block(const AttnKArgs a) {
     const int ldq = 256 + LDS_PAD, ldp = a.Sp + LDS_PAD;
     float* Qs = smem;                  // [32][264]  Q tile, later the O tile
     float* Ps = smem + TILE_M * ldq;   // [32][Sp+8] scores / probabilities, later the out_proj tile
-    const int b = blockIdx.y, q0 = blockIdx.x * TILE_M;
+    // XCD-aware mapping: blocks L and L+8 share an XCD (and its L2); all query tiles of one sequence re-read
+    // that sequence's K/V, so they are placed on the same XCD (speed only -- any placement is correct)
+    int b = blockIdx.y, qt = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {
+        const int L = blockIdx.x + gridDim.x * blockIdx.y, r = L & 7, q = L >> 3;
+        b = r + 8 * (q / (int)gridDim.x);
+        qt = q % (int)gridDim.x;
+    }
+    const int q0 = qt * TILE_M;
     const size_t base = (size_t)b * a.S;
     const int n_valid_keys = min(a.S, a.n_prefix + a.lengths[b]);
 
