@@ -68,6 +68,17 @@ def den_algorithmic_bytes(den, B, N, steps):
     return steps * per_step + B * per_sample
 
 
+def measured_traffic(weights, B, steps):
+    """HBM-side bytes per launch of the sampling kernel from the committed rocprofv3 PMC passes
+    (scripts/gpu_traffic.sh; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), if this exact config was profiled."""
+    path = os.path.join(REPO, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(f"{weights}_B{B}_steps{steps}")
+    except OSError:
+        return None
+
+
 def cpu_baseline(B, budget_s=12.0):
     """The numpy oracle (a port of the reference CPU path, pinned to it by tests/golden) on this host."""
     from oracle import mld_oracle as O
@@ -100,6 +111,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU per pass (BASELINE configs[1]: 32)")
     ap.add_argument("--weights", default="bf16", choices=["fp32", "bf16"], help="denoiser weight image dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scheduler", default="ddim", choices=["ddim", "ddpm"], help="ddpm = 1000-step ancestral sampling (BASELINE configs[4])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,6 +129,13 @@ def main():
 
     B = args.batch
     vae, den, sch = build_models(dev, args.weights)
+    n_infer = DDIM_STEPS
+    if args.scheduler == "ddpm":
+        from seeme_amd.schedulers import DDPMScheduler
+        sch = DDPMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                            variance_type="fixed_small", clip_sample=False)
+        sch.set_timesteps(1000)
+        n_infer = 1000
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     motion = torch.randn(B, T_FRAMES, NFEATS, generator=g).to(dev)
     latents = torch.randn(B, 1, 256, generator=g).to(dev)
@@ -146,12 +165,12 @@ def main():
 
     # dominant kernel: the persistent DDIM kernel
     loop_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    alg_bytes = den_algorithmic_bytes(den, B, 1, DDIM_STEPS)
+    alg_bytes = den_algorithmic_bytes(den, B, 1, n_infer)
     achieved = alg_bytes / (loop_ms * 1e-3) / 1e9
 
     if rank == 0:
         res = {
-            "metric": "sampled seqs/sec (T=196, 50 DDIM steps)",
+            "metric": "sampled seqs/sec (T=196, 50 DDIM steps)" if args.scheduler == "ddim" else "sampled seqs/sec (T=196, 1000 DDPM steps)",
             "value": round(world * B * args.steps / dt, 2),
             "unit": "seqs/s",
             "n_gpus": world,
@@ -165,11 +184,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"config_mld_egobody interactee-only: VAE encode -> 50-step DDIM -> VAE decode, "
                                    f"B={B}/GPU, T=196, nfeats=132, random-init recipe weights",
-                       "batch_per_gpu": B, "seq_len": T_FRAMES, "ddim_steps": DDIM_STEPS,
+                       "batch_per_gpu": B, "seq_len": T_FRAMES, "ddim_steps": n_infer,
                        "parallelism": f"dp{world} (independent shards, no collective on the data path)"},
             "roofline": {"bound": "hbm", "kernel": "k_den_sample (persistent DDIM loop)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.weights, B, n_infer),
                          "ms_per_launch": round(loop_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
         if world == 1 and not args.no_cpu_baseline:

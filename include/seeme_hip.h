@@ -228,6 +228,19 @@ size_t seeme_pointnet_workspace_bytes(int B, int P);
 int seeme_pointnet_encode(const SeemePointnetWeights* w, const float* points, int B, int P, float* out,
                           void* workspace, size_t ws_bytes, void* stream);
 
+/* bf16-MFMA variant (fp32 accumulation): the same weights as bf16 copies packed in MFMA fragment order,
+ * Wp[((n/16) * (K/32) + k/32) * 64 + lane][8] = W[16*(n/16) + (lane&15)][32*(k/32) + 8*(lane>>4) .. +7];
+ * one fused kernel per ResnetBlockFC on 128-point tiles, max-pool folded into the epilogue.  Results differ
+ * from the fp32 path by bf16 rounding of weights and activations (tolerance stated in the tests). */
+typedef struct {
+    const uint16_t* fc0[4];     /* block_i.fc_0.weight   [256,512] packed */
+    const uint16_t* fc1[4];     /* block_i.fc_1.weight   [256,256] packed */
+    const uint16_t* sc[4];      /* block_i.shortcut.weight [256,512] packed */
+} SeemePointnetBf16;
+size_t seeme_pointnet_bf16_workspace_bytes(int B, int P);
+int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const SeemePointnetBf16* wb, const float* points,
+                               int B, int P, float* out, void* workspace, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

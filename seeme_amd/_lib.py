@@ -76,6 +76,10 @@ class PointnetWeights(C.Structure):
                 ("fc1_w", fp * 4), ("fc1_b", fp * 4), ("sc_w", fp * 4), ("fcc_w", fp), ("fcc_b", fp)]
 
 
+class PointnetBf16(C.Structure):
+    _fields_ = [("fc0", fp * 4), ("fc1", fp * 4), ("sc", fp * 4)]
+
+
 GEO_AA_TO_QUAT, GEO_AA_TO_ROTMAT, GEO_QUAT_TO_ROTMAT, GEO_ROT6D_PROHMR, GEO_ROT6D_DIFFUSION = range(5)
 
 # name -> (restype, argtypes); every symbol of include/seeme_hip.h
@@ -95,6 +99,9 @@ _SIGNATURES = {
     "seeme_renorm": (C.c_int, [fp, fp, fp, fp, C.c_long, C.c_int, fp]),
     "seeme_pointnet_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "seeme_pointnet_encode": (C.c_int, [C.POINTER(PointnetWeights), fp, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
+    "seeme_pointnet_bf16_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "seeme_pointnet_encode_bf16": (C.c_int, [C.POINTER(PointnetWeights), C.POINTER(PointnetBf16), fp, C.c_int, C.c_int, fp, fp,
+                                             C.c_size_t, fp]),
     "seeme_smpl_workspace_bytes": (C.c_size_t, [C.c_int]),
     "seeme_smpl_lbs": (C.c_int, [C.POINTER(SmplModel), fp, fp, C.c_int, fp, C.c_int, fp, fp, fp, C.c_size_t, fp]),
 }

@@ -23,8 +23,11 @@ class _ResnetBlockFCParams(nn.Module):
 
 
 class ResnetPointnet(nn.Module):
-    def __init__(self, out_dim: int = 512, hidden_dim: int = 256):
+    def __init__(self, out_dim: int = 512, hidden_dim: int = 256, precision: str = "fp32"):
         super().__init__()
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' (fp32 MFMA, parity path) or 'bf16' (fused bf16-MFMA blocks)")
+        self.precision = precision
         if hidden_dim != 256:
             raise NotImplementedError("accelerated path: hidden_dim 256 (ProHMRScene builds ResnetPointnet(512, 256))")
         self.out_dim = out_dim
@@ -53,7 +56,18 @@ class ResnetPointnet(nn.Module):
             w.fc1_w[i], w.fc1_b[i] = L.ptr(blk.fc_1.weight), L.ptr(blk.fc_1.bias)
             w.sc_w[i] = L.ptr(blk.shortcut.weight)
         w.fcc_w, w.fcc_b = L.ptr(self.fc_c.weight), L.ptr(self.fc_c.bias)
-        self._wcache = (fpnt, w, (posw,))
+        with torch.no_grad():
+            bf = [getattr(self, f"block_{i}") for i in range(4)]
+            def pack(W):   # [N,K] -> MFMA fragment order [N/16][K/32][kq=4][r=16][8] (1 KiB per wave-load)
+                N, K = W.shape
+                return W.to(torch.bfloat16).view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+            fc0 = [pack(b.fc_0.weight) for b in bf]
+            fc1 = [pack(b.fc_1.weight) for b in bf]
+            sc = [pack(b.shortcut.weight) for b in bf]
+        wb = L.PointnetBf16()
+        for i in range(4):
+            wb.fc0[i], wb.fc1[i], wb.sc[i] = fc0[i].data_ptr(), fc1[i].data_ptr(), sc[i].data_ptr()
+        self._wcache = (fpnt, w, (posw, fc0, fc1, sc), wb)
         return w
 
     def forward(self, p: torch.Tensor) -> torch.Tensor:
@@ -63,10 +77,17 @@ class ResnetPointnet(nn.Module):
         assert three == 3
         p = p.contiguous()
         out = torch.empty(B, self.out_dim, device=p.device, dtype=torch.float32)
-        need = L.lib().seeme_pointnet_workspace_bytes(B, P)
+        bf16 = self.precision == "bf16"
+        need = (L.lib().seeme_pointnet_bf16_workspace_bytes if bf16 else L.lib().seeme_pointnet_workspace_bytes)(B, P)
         if self._ws is None or self._ws.numel() < need or self._ws.device != p.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=p.device)
         w = self._weights()
-        L.check(L.lib().seeme_pointnet_encode(C.byref(w), p.data_ptr(), B, P, out.data_ptr(), self._ws.data_ptr(),
-                                               self._ws.numel(), L.current_stream()), "seeme_pointnet_encode")
+        if bf16:
+            wb = self._wcache[3]
+            L.check(L.lib().seeme_pointnet_encode_bf16(C.byref(w), C.byref(wb), p.data_ptr(), B, P, out.data_ptr(),
+                                                        self._ws.data_ptr(), self._ws.numel(), L.current_stream()),
+                    "seeme_pointnet_encode_bf16")
+        else:
+            L.check(L.lib().seeme_pointnet_encode(C.byref(w), p.data_ptr(), B, P, out.data_ptr(), self._ws.data_ptr(),
+                                                   self._ws.numel(), L.current_stream()), "seeme_pointnet_encode")
         return out
