@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU per pass (BASELINE configs[1]: 32)")
-    ap.add_argument("--weights", default="bf16", choices=["fp32", "bf16"], help="denoiser weight image dtype")
+    ap.add_argument("--weights", default="bf16", choices=["fp32", "bf16", "fp16"], help="denoiser weight image dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scheduler", default="ddim", choices=["ddim", "ddpm"], help="ddpm = 1000-step ancestral sampling (BASELINE configs[4])")
     args = ap.parse_args()
@@ -180,7 +180,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.weights == "fp32" else "f32 (bf16 denoiser weights)",
+            "dtype": "f32" if args.weights == "fp32" else f"f32 ({args.weights} denoiser weights)",
             "data": "synthetic",
             "config": {"workload": f"config_mld_egobody interactee-only: VAE encode -> 50-step DDIM -> VAE decode, "
                                    f"B={B}/GPU, T=196, nfeats=132, random-init recipe weights",

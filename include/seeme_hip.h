@@ -113,13 +113,13 @@ int seeme_vae_decode(const SeemeVaeWeights* w, const float* z, const int32_t* le
  * mdiff_transformer.py:257-304) and MLD._diffusion_reverse (mld/models/modeltype/mld.py:432-511).
  *
  * Weight image: the host packs the state_dict once into
- *   wg : GEMV-layout matrices, element type fp32 or bf16 (wdtype 0 / 1); a [N,K] PyTorch matrix is
- *        stored as [K/KV][N][KV] with KV = 4 (fp32) or 8 (bf16) so that a wave reads 1 KiB contiguous;
+ *   wg : GEMV-layout matrices, element type fp32, bf16 or fp16 (wdtype 0 / 1 / 2); a [N,K] PyTorch matrix is
+ *        stored as [K/KV][N][KV] with KV = 4 (fp32) or 8 (16-bit) so that a wave reads 1 KiB contiguous;
  *   vp : fp32 vectors (biases, LayerNorm params, pe row 0);
  * in the order documented in seeme_amd/csrc/den_layout.h; seeme_den_layout() exports the offsets.
  */
 typedef struct {
-    const void*  wg;   int wdtype;       /* 0 = fp32, 1 = bf16 */
+    const void*  wg;   int wdtype;       /* 0 = fp32, 1 = bf16, 2 = fp16 */
     const float* vp;
     const int64_t* layout;               /* device copy of the seeme_den_layout() table (155 int64) */
     int nhead;                           /* 1, 2 or 4 */

@@ -24,8 +24,9 @@
 #endif
 
 // ------------------------------------------------------------------ weight element types
-struct WF32 { typedef float T; static constexpr int KV = 4; };      // 16-B vector = 4 weights
-struct WBF16 { typedef uint16_t T; static constexpr int KV = 8; };  // 16-B vector = 8 weights
+struct WF32 { typedef float T; static constexpr int KV = 4; static constexpr bool HALF = false; };      // 16-B vector = 4 weights
+struct WBF16 { typedef uint16_t T; static constexpr int KV = 8; static constexpr bool HALF = false; };  // 16-B vector = 8 bf16 weights
+struct WF16 { typedef uint16_t T; static constexpr int KV = 8; static constexpr bool HALF = true; };    // 16-B vector = 8 fp16 weights
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -105,6 +106,16 @@ __device__ __forceinline__ void consume(const WBuf& b, const float* __restrict__
             if constexpr (WT::KV == 4) {
                 acc[s][0] += f2{__uint_as_float(u.x), __uint_as_float(u.y)} * f2{x0.x, x0.y};
                 acc[s][1] += f2{__uint_as_float(u.z), __uint_as_float(u.w)} * f2{x0.z, x0.w};
+            } else if constexpr (WT::HALF) {
+                // fp16 weights: v_fma_mix_f32 takes the half operand directly (no unpack instructions)
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const float4 x1 = *reinterpret_cast<const float4*>(xp + 4);
+                const unsigned ux = u.x, uy = u.y, uz = u.z, uw = u.w;   // (bit_cast straight from a vector element picks element 0)
+                const h2 w0 = __builtin_bit_cast(h2, ux), w1 = __builtin_bit_cast(h2, uy), w2 = __builtin_bit_cast(h2, uz), w3 = __builtin_bit_cast(h2, uw);
+                acc[s][0].x = fmaf((float)w0.x, x0.x, acc[s][0].x); acc[s][0].y = fmaf((float)w0.y, x0.y, acc[s][0].y);
+                acc[s][1].x = fmaf((float)w1.x, x0.z, acc[s][1].x); acc[s][1].y = fmaf((float)w1.y, x0.w, acc[s][1].y);
+                acc[s][0].x = fmaf((float)w2.x, x1.x, acc[s][0].x); acc[s][0].y = fmaf((float)w2.y, x1.y, acc[s][0].y);
+                acc[s][1].x = fmaf((float)w3.x, x1.z, acc[s][1].x); acc[s][1].y = fmaf((float)w3.y, x1.w, acc[s][1].y);
             } else {
                 const float4 x1 = *reinterpret_cast<const float4*>(xp + 4);
                 acc[s][0] += f2{bf_lo(u.x), bf_hi(u.x)} * f2{x0.x, x0.y};
@@ -593,7 +604,8 @@ extern "C" int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeS
     hipStream_t st = (hipStream_t)stream;
     if (w->wdtype == 0) return a->cfg ? launch_den<WF32, 2>(ka, st) : launch_den<WF32, 1>(ka, st);
     if (w->wdtype == 1) return a->cfg ? launch_den<WBF16, 2>(ka, st) : launch_den<WBF16, 1>(ka, st);
-    return seeme_fail("denoiser_sample: wdtype must be 0 (fp32) or 1 (bf16)");
+    if (w->wdtype == 2) return a->cfg ? launch_den<WF16, 2>(ka, st) : launch_den<WF16, 1>(ka, st);
+    return seeme_fail("denoiser_sample: wdtype must be 0 (fp32), 1 (bf16) or 2 (fp16)");
 }
 
 extern "C" int seeme_den_layout(int ff_sa, int ff, int64_t* out, int cap) {

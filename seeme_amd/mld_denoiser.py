@@ -139,8 +139,8 @@ class MldDenoiser(nn.Module):
             raise NotImplementedError("accelerated path: latent_dim [1,256], text_encoded_dim 256, 5 layers")
         if num_heads not in (1, 2, 4):
             raise NotImplementedError("accelerated path: num_heads in {1,2,4}")
-        if weight_dtype not in ("fp32", "bf16"):
-            raise ValueError("weight_dtype must be 'fp32' or 'bf16'")
+        if weight_dtype not in ("fp32", "bf16", "fp16"):
+            raise ValueError("weight_dtype must be 'fp32', 'bf16' or 'fp16'")
         self.weight_dtype = weight_dtype
 
         d = self.latent_dim
@@ -172,9 +172,10 @@ class MldDenoiser(nn.Module):
             L.require_cuda(p, "MldDenoiser parameter")
         dev = self.query_pos.pe.device
         layers, pe0, fnw, fnb, wg_total, vp_total = self._layout()
-        bf16 = self.weight_dtype == "bf16"
+        bf16 = self.weight_dtype != "fp32"          # any 16-bit image: 8 weights per 16-byte vector
         KV = 8 if bf16 else 4
-        wg = torch.zeros(wg_total, dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+        wdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[self.weight_dtype]
+        wg = torch.zeros(wg_total, dtype=wdt, device=dev)
         vp = torch.zeros(vp_total, dtype=torch.float32, device=dev)
 
         def put_w(off, W):   # PyTorch [N,K] -> GEMV layout [K/KV][N][KV]
@@ -223,7 +224,7 @@ class MldDenoiser(nn.Module):
             ones, zeros = torch.ones(256, device=dev), torch.zeros(256, device=dev)
         lay_dev = torch.tensor(self._layout_vals, dtype=torch.int64, device=dev)
         w = L.DenoiserWeights()
-        w.wg, w.wdtype, w.vp, w.layout = wg.data_ptr(), 1 if bf16 else 0, vp.data_ptr(), lay_dev.data_ptr()
+        w.wg, w.wdtype, w.vp, w.layout = wg.data_ptr(), {"fp32": 0, "bf16": 1, "fp16": 2}[self.weight_dtype], vp.data_ptr(), lay_dev.data_ptr()
         w.nhead, w.ff_sa, w.ff = self.num_heads, 1024, self.ff_size
         w.kv_cat_w, w.kv_cat_b, w.style_cat_w, w.style_cat_b = kv_w.data_ptr(), kv_b.data_ptr(), st_w.data_ptr(), st_b.data_ptr()
         te = self.time_embedding

@@ -154,14 +154,22 @@ def test_denoiser_golden(dev, N):
     assert rel_err(y.cpu().numpy(), g["out_tvec"]) < TOL_F32
 
 
-def test_denoiser_bf16_weights(dev):
+@pytest.mark.parametrize("wd,tol", [("bf16", TOL_BF16W), ("fp16", 4e-3)])
+def test_denoiser_16bit_weights(dev, wd, tol):
+    """16-bit weight images (activations / accumulation stay fp32): error is MEASURED and reported; the 1e-4 gate
+    applies to the fp32 image only."""
     g = load_golden("denoiser_N1.npz")
-    den = make_den(dev, weight_dtype="bf16")
+    den = make_den(dev, weight_dtype=wd)
     s, c = torch.from_numpy(g["sample"]).to(dev), torch.from_numpy(g["cond"]).to(dev)
     y = den(sample=s, timestep=torch.tensor(501), encoder_hidden_states=c)[0]
     e = rel_err(y.cpu().numpy(), g["out_t501"])
-    print("bf16-weight denoiser rel err", e)
-    assert e < TOL_BF16W
+    gl = load_golden("ddim50_N1_B3.npz")
+    sch = _sched()
+    sch.set_timesteps(50)
+    z = den.sample_loop(torch.from_numpy(gl["latents"]).to(dev), torch.from_numpy(gl["cond_bf"]).to(dev), sch)
+    e50 = rel_err(z.cpu().numpy(), gl["out"])
+    print(f"{wd}-weight denoiser rel err: one forward {e:.3e}, 50-step DDIM latent {e50:.3e}")
+    assert e < tol
 
 
 def _sched(kind="ddim"):
