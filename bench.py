@@ -36,12 +36,13 @@ def ablation():
                                  DIFF_PE_TYPE="mld", MD_TRANS=True)
 
 
-def build_models(dev, weight_dtype):
+def build_models(dev, weight_dtype, vae_precision="fp32"):
     from seeme_amd.mld_denoiser import MldDenoiser
     from seeme_amd.mld_vae import MldVae
     from seeme_amd.schedulers import DDIMScheduler
     from seeme_amd.weights_recipe import load_recipe_
-    vae = load_recipe_(MldVae(ablation(), nfeats=NFEATS, latent_dim=[1, 256], arch="encoder_decoder")).to(dev).eval()
+    vae = load_recipe_(MldVae(ablation(), nfeats=NFEATS, latent_dim=[1, 256], arch="encoder_decoder",
+                             precision=vae_precision)).to(dev).eval()
     den = load_recipe_(MldDenoiser(ablation(), nfeats=NFEATS, condition=["text", "interactee"], latent_dim=[1, 256],
                                    ff_size=128, num_layers=5, num_heads=1, weight_dtype=weight_dtype)).to(dev).eval()
     sch = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
@@ -109,7 +110,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU per pass (BASELINE configs[1]: 32)")
-    ap.add_argument("--weights", default="bf16", choices=["fp32", "bf16", "fp16"], help="denoiser weight image dtype")
+    ap.add_argument("--weights", default="fp16", choices=["fp32", "bf16", "fp16"], help="denoiser weight image dtype")
+    ap.add_argument("--vae", default="fp16", choices=["fp32", "fp16"], help="VAE MFMA operand type (fp32 = exact parity path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scheduler", default="ddim", choices=["ddim", "ddpm"], help="ddpm = 1000-step ancestral sampling (BASELINE configs[4])")
     args = ap.parse_args()
@@ -128,7 +130,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.batch
-    vae, den, sch = build_models(dev, args.weights)
+    vae, den, sch = build_models(dev, args.weights, args.vae)
     n_infer = DDIM_STEPS
     if args.scheduler == "ddpm":
         from seeme_amd.schedulers import DDPMScheduler
@@ -180,7 +182,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.weights == "fp32" else f"f32 ({args.weights} denoiser weights)",
+            "dtype": "f32" if (args.weights == "fp32" and args.vae == "fp32") else
+                     f"f32 accumulate ({args.weights} denoiser weights, {args.vae} VAE MFMA operands)",
             "data": "synthetic",
             "config": {"workload": f"config_mld_egobody interactee-only: VAE encode -> 50-step DDIM -> VAE decode, "
                                    f"B={B}/GPU, T=196, nfeats=132, random-init recipe weights",

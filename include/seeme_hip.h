@@ -78,6 +78,15 @@ typedef struct {
     const float *norm_w, *norm_b;        /* stack-final LayerNorm */
 } SeemeSkipStack;
 
+/* fp16 copies of the VAE matrices packed in MFMA fragment order (see SeemePointnetBf16 for the layout; N padded to
+ * 16, K padded to 32): the throughput mode of the VAE (fp16 MFMA operands, fp32 accumulation / residual stream). */
+typedef struct { const uint16_t *in_w, *out_w, *l1_w, *l2_w; } SeemeXfLayerH;
+typedef struct {
+    SeemeXfLayerH enc[SEEME_NLAYERS], dec[SEEME_NLAYERS];
+    const uint16_t *enc_skip[2], *dec_skip[2];
+    const uint16_t *emb_w, *fin_w, *ca_fold_w;
+} SeemeVaeWeightsH;
+
 typedef struct {
     int nfeats;                 /* F */
     int ff;                     /* 128 (hard-coded mld_vae.py:53) */
@@ -93,6 +102,7 @@ typedef struct {
      * c_l = ca_fold_w[l*256:(l+1)*256] z + ca_fold_b[...],  ca_fold_w = out_proj_l . W_v_l,  ca_fold_b = out_proj_l b_v_l + b_o_l */
     const float* ca_fold_w;     /* [5*256, 256] */
     const float* ca_fold_b;     /* [5*256] */
+    const SeemeVaeWeightsH* h16; /* NULL: fp32-exact MFMA path (parity); else fp16-operand MFMA path */
 } SeemeVaeWeights;
 
 size_t seeme_vae_workspace_bytes(int B, int T);

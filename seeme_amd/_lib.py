@@ -44,10 +44,30 @@ class SkipStack(C.Structure):
                 ("norm_w", fp), ("norm_b", fp)]
 
 
+class XfLayerH(C.Structure):
+    _fields_ = [(n, fp) for n in ("in_w", "out_w", "l1_w", "l2_w")]
+
+
+class VaeWeightsH(C.Structure):
+    _fields_ = [("enc", XfLayerH * NLAYERS), ("dec", XfLayerH * NLAYERS), ("enc_skip", fp * 2), ("dec_skip", fp * 2),
+                ("emb_w", fp), ("fin_w", fp), ("ca_fold_w", fp)]
+
+
+def pack_mfma16(W, dtype):
+    """[N,K] matrix -> 16-bit copy in MFMA fragment order [N/16][K/32][kq=4][r=16][8] (N padded to 16, K to 32):
+    every wave-load of a B fragment is then 1 KiB contiguous."""
+    import torch
+    N, K = W.shape
+    Np, Kp = (N + 15) // 16 * 16, (K + 31) // 32 * 32
+    Wz = torch.zeros(Np, Kp, device=W.device, dtype=dtype)
+    Wz[:N, :K] = W.detach().to(dtype)
+    return Wz.view(Np // 16, 16, Kp // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
 class VaeWeights(C.Structure):
     _fields_ = [("nfeats", C.c_int), ("ff", C.c_int), ("token", fp), ("pe_enc", fp), ("pe_dec", fp),
                 ("emb_w", fp), ("emb_ldw", C.c_int), ("emb_b", fp), ("fin_w", fp), ("fin_b", fp),
-                ("enc", SkipStack), ("dec", SkipStack), ("ca_fold_w", fp), ("ca_fold_b", fp)]
+                ("enc", SkipStack), ("dec", SkipStack), ("ca_fold_w", fp), ("ca_fold_b", fp), ("h16", fp)]
 
 
 class DenoiserWeights(C.Structure):

@@ -32,3 +32,8 @@ int seeme_launch_linear(const LinearKArgs& ka, hipStream_t st);
 int seeme_linear_simple(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias,
                         float* Y, int ldy, int M, int N, int K, int act, int pre_act,
                         const float* pre_ln_w, const float* pre_ln_b);
+
+int seeme_vae_encode_h16(const SeemeVaeWeights* w, const float* features, const int32_t* lengths, int B, int T, float* mu,
+                         void* workspace, hipStream_t st);
+int seeme_vae_decode_h16(const SeemeVaeWeights* w, const float* z, const int32_t* lengths, int B, int T, float* feats,
+                         void* workspace, hipStream_t st);

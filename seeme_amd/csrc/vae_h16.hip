@@ -1,0 +1,536 @@
+// vae_h16.hip -- the VAE row-tile kernels with fp16 MFMA operands (v_mfma_f32_16x16x32_f16, fp32
+// accumulation): the throughput mode of MldVae.encode / decode.  Same structure as vae_kernels.hip (32-row tiles,
+// 4 waves x 64 columns); what changes is the operand path:
+//   * activations entering a GEMM are rounded to fp16 in LDS (row stride K+16 halves: conflict-free b128 reads);
+//   * weights are fp16 copies packed in MFMA fragment order (one 1 KiB contiguous load per wave and k-block);
+//   * the QKV projection writes q|k as fp16 rows and V TRANSPOSED ([B][256][Sp]) so that the P.V contraction
+//     (over keys) also reads 16 contiguous bytes per lane;
+//   * the residual stream, LayerNorm, softmax and all accumulators stay fp32.
+// Error vs the fp32 path is measured in tests/test_gpu_parity.py (fp16: 10-bit mantissa operands).
+#include "common.hpp"
+#include "api_util.hpp"
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+#define HPAD 16
+
+__device__ __forceinline__ unsigned short f2h(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
+
+template <int MTL, int NTL, typename LoadB>
+__device__ __forceinline__ void tile_gemm_h16(const unsigned short* __restrict__ As, int lda, int K32, LoadB loadb,
+                                              f32x4 (&acc)[MTL][NTL]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+    const unsigned short* ap = As + r * lda + 8 * kq;
+    constexpr int PF = 2;
+    uint4 br[PF][NTL];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) br[u][nt] = loadb(nt, u < K32 ? u : K32 - 1);
+    uint4 an[MTL];
+#pragma unroll
+    for (int mt = 0; mt < MTL; ++mt) an[mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda);
+    for (int kb0 = 0; kb0 < K32; kb0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int kb = kb0 + u;
+            if (kb < K32) {
+                h16x8 b[NTL], a[MTL];
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) b[nt] = __builtin_bit_cast(h16x8, br[u][nt]);
+#pragma unroll
+                for (int mt = 0; mt < MTL; ++mt) a[mt] = __builtin_bit_cast(h16x8, an[mt]);
+                const int kn = (kb + PF < K32) ? kb + PF : K32 - 1;
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) br[u][nt] = loadb(nt, kn);
+                const int ka = (kb + 1 < K32) ? kb + 1 : kb;
+#pragma unroll
+                for (int mt = 0; mt < MTL; ++mt) an[mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda + ka * 32);
+#pragma unroll
+                for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+}
+// B fragments from fragment-packed weights: Wp[(ntile*kstride + kb)*64 + lane]; n-tiles clamped to ntiles-1
+template <int MTL, int NTL>
+__device__ __forceinline__ void gemm_packed(const unsigned short* As, int lda, const uint4* __restrict__ Wp, int kstride,
+                                            int ntile0, int ntiles, int K32, f32x4 (&acc)[MTL][NTL]) {
+    const int lane = threadIdx.x & 63;
+    tile_gemm_h16<MTL, NTL>(As, lda, K32, [&](int nt, int kb) {
+        int t = ntile0 + nt; t = t < ntiles ? t : ntiles - 1;
+        return Wp[((size_t)t * kstride + kb) * 64 + lane];
+    }, acc);
+}
+// B fragments from a row-major fp16 matrix Bm[n][k] (rows clamped to n_valid-1)
+template <int MTL, int NTL>
+__device__ __forceinline__ void gemm_rows(const unsigned short* As, int lda, const unsigned short* __restrict__ Bm, int ldb,
+                                          int n0, int n_valid, int K32, f32x4 (&acc)[MTL][NTL]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+    tile_gemm_h16<MTL, NTL>(As, lda, K32, [&](int nt, int kb) {
+        int n = n0 + nt * 16 + r; n = n < n_valid ? n : n_valid - 1;
+        return *reinterpret_cast<const uint4*>(Bm + (size_t)n * ldb + kb * 32 + 8 * kq);
+    }, acc);
+}
+// accumulators -> fp16 LDS tile (the next GEMM's A operand), + bias, activation
+template <int MTL, int NTL>
+__device__ __forceinline__ void acc_store_h16(const f32x4 (&acc)[MTL][NTL], unsigned short* __restrict__ Hs, int ldh, int c0,
+                                              const float* __restrict__ bias, int act) {
+    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int c = c0 + nt * 16 + r;
+        const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Hs[(mt * 16 + 4 * kq + i) * ldh + c] = f2h(act_apply(acc[mt][nt][i] + bv, act));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct LinearHArgs {
+    LinearKArgs k;              // same meaning as the fp32 kernel (k.a.W unused)
+    const uint4* wp; int kstride; int ntiles;
+    int qkv_mode;               // 1: N = 768 -> q|k fp16 rows [M][512] and V transposed [B][256][spv]
+    unsigned short* qk; unsigned short* vt; int S, spv;
+};
+
+__global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LinearKArgs& ka = ha.k;
+    const SeemeLinearArgs& a = ka.a;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Kp = (a.K + 31) & ~31;
+    const int lda_f = Kp + LDS_PAD, lda_h = Kp + HPAD;
+    float* Af = smem;                                                  // [32][Kp+8] fp32 staging (pre-LN / act)
+    float* Cs = Af + TILE_M * lda_f;                                   // [32][264]
+    unsigned short* Ah = reinterpret_cast<unsigned short*>(Cs + TILE_M * (CH_N + LDS_PAD));   // [32][Kp+16] fp16
+    const int ldc = CH_N + LDS_PAD;
+    const int m0 = blockIdx.x * TILE_M, cn0 = blockIdx.y * CH_N;
+
+    const bool fast = (a.pre_ln_w == nullptr) && ((a.K & 3) == 0) && ((a.K1 & 3) == 0) && ((a.lda & 3) == 0) &&
+                      ((reinterpret_cast<size_t>(a.A) & 15) == 0) &&
+                      (a.A2 == nullptr || (((a.lda2 & 3) == 0) && ((reinterpret_cast<size_t>(a.A2) & 15) == 0)));
+    if (fast) {   // float4 in, 4 halves out, no fp32 staging tile
+        const int Kp4 = Kp >> 2, K4 = a.K >> 2;
+        for (int idx = tid; idx < TILE_M * Kp4; idx += 256) {
+            const int row = idx / Kp4, c4 = idx - row * Kp4, m = m0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < a.M && c4 < K4) {
+                int prow = m;
+                if (ka.seq_in > 0) prow = (m / ka.seq_in) * ka.in_stride + (m % ka.seq_in) + ka.in_off;
+                v = (4 * c4 < a.K1) ? *reinterpret_cast<const float4*>(a.A + (size_t)prow * a.lda + 4 * c4)
+                                    : *reinterpret_cast<const float4*>(a.A2 + (size_t)prow * a.lda2 + (4 * c4 - a.K1));
+                if (a.pre_act != SEEME_ACT_NONE)
+                    v = make_float4(act_apply(v.x, a.pre_act), act_apply(v.y, a.pre_act), act_apply(v.z, a.pre_act), act_apply(v.w, a.pre_act));
+            }
+            const unsigned lo = (unsigned)f2h(v.x) | ((unsigned)f2h(v.y) << 16), hi = (unsigned)f2h(v.z) | ((unsigned)f2h(v.w) << 16);
+            *reinterpret_cast<uint2*>(Ah + row * lda_h + 4 * c4) = make_uint2(lo, hi);
+        }
+        __syncthreads();
+    } else {
+        for (int idx = tid; idx < TILE_M * Kp; idx += 256) {
+            const int row = idx / Kp, c = idx - row * Kp, m = m0 + row;
+            float v = 0.f;
+            if (m < a.M && c < a.K) {
+                int prow = m;
+                if (ka.seq_in > 0) prow = (m / ka.seq_in) * ka.in_stride + (m % ka.seq_in) + ka.in_off;
+                v = (c < a.K1) ? a.A[(size_t)prow * a.lda + c] : a.A2[(size_t)prow * a.lda2 + (c - a.K1)];
+            }
+            Af[row * lda_f + c] = v;
+        }
+        __syncthreads();
+        if (a.pre_ln_w != nullptr) {
+            for (int rr = 0; rr < 8; ++rr) {
+                const int row = wave * 8 + rr;
+                float s = 0.f;
+                for (int c = lane; c < a.K; c += 64) s += Af[row * lda_f + c];
+                const float mean = wave_sum(s) / (float)a.K;
+                float q = 0.f;
+                for (int c = lane; c < a.K; c += 64) { const float d = Af[row * lda_f + c] - mean; q += d * d; }
+                const float rs = 1.f / sqrtf(wave_sum(q) / (float)a.K + a.eps);
+                for (int c = lane; c < a.K; c += 64) Af[row * lda_f + c] = (Af[row * lda_f + c] - mean) * rs * a.pre_ln_w[c] + a.pre_ln_b[c];
+            }
+            __syncthreads();
+        }
+        for (int idx = tid; idx < TILE_M * Kp; idx += 256) {
+            const int row = idx / Kp, c = idx - row * Kp;
+            Ah[row * lda_h + c] = f2h(c < a.K ? act_apply(Af[row * lda_f + c], a.pre_act) : 0.f);
+        }
+        __syncthreads();
+    }
+
+    f32x4 acc[2][4];
+    acc_zero(acc);
+    const int n0 = cn0 + wave * 64;
+    if (n0 < a.N) gemm_packed<2, 4>(Ah, lda_h, ha.wp, ha.kstride, n0 >> 4, ha.ntiles, Kp >> 5, acc);
+    acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, a.bias, cn0, a.N, a.act);
+    __syncthreads();
+
+    if (ha.qkv_mode) {
+        if (blockIdx.y < 2) {          // q | k -> fp16 rows [M][512]
+            for (int idx = tid; idx < TILE_M * 64; idx += 256) {
+                const int row = idx >> 6, c4 = (idx & 63) * 4, m = m0 + row;
+                if (m >= a.M) continue;
+                const float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + c4);
+                const unsigned lo = (unsigned)f2h(v.x) | ((unsigned)f2h(v.y) << 16), hi = (unsigned)f2h(v.z) | ((unsigned)f2h(v.w) << 16);
+                *reinterpret_cast<uint2*>(ha.qk + (size_t)m * 512 + blockIdx.y * 256 + c4) = make_uint2(lo, hi);
+            }
+        } else {                       // v -> transposed [b][d][s]: lanes <-> rows (consecutive s), loop over d
+            const int row = tid & 31, dg = tid >> 5, m = m0 + row;
+            if (m < a.M) {
+                const int b = m / ha.S, s = m - b * ha.S;
+                unsigned short* base = ha.vt + ((size_t)b * 256) * ha.spv + s;
+                for (int j = 0; j < 32; ++j) {
+                    const int d = dg * 32 + j;
+                    base[(size_t)d * ha.spv] = f2h(Cs[row * ldc + d]);
+                }
+            }
+        }
+        return;
+    }
+    const bool vec_ok = ((a.ldy & 3) == 0) && ((a.N & 3) == 0);
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr, m = m0 + row;
+        if (m >= a.M) continue;
+        int orow = m;
+        if (ka.seq_in > 0) orow = (m / ka.seq_in) * ka.out_stride + (m % ka.seq_in) + ka.out_off;
+        const int c = lane * 4, g = cn0 + c;
+        float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + c);
+        if (a.res != nullptr) {
+            const size_t rrow = ka.res_mode == 1 ? (size_t)((m % ka.seq_in) + ka.res_off)
+                              : ka.res_mode == 2 ? (size_t)(m / ka.seq_in) : (size_t)orow;
+            const float* rp = a.res + rrow * a.ldr + g;
+            if (g + 0 < a.N) v.x += rp[0];
+            if (g + 1 < a.N) v.y += rp[1];
+            if (g + 2 < a.N) v.z += rp[2];
+            if (g + 3 < a.N) v.w += rp[3];
+        }
+        if (a.ln_w != nullptr) v = wave_layernorm256(v, a.ln_w, a.ln_b, a.eps);
+        float* yp = a.Y + (size_t)orow * a.ldy + g;
+        if (vec_ok && g + 3 < a.N) {
+            *reinterpret_cast<float4*>(yp) = v;
+        } else {
+            if (g + 0 < a.N) yp[0] = v.x;
+            if (g + 1 < a.N) yp[1] = v.y;
+            if (g + 2 < a.N) yp[2] = v.z;
+            if (g + 3 < a.N) yp[3] = v.w;
+        }
+    }
+}
+
+static int launch_linear_h(const LinearHArgs& ha, hipStream_t st) {
+    const SeemeLinearArgs& a = ha.k.a;
+    const int Kp = (a.K + 31) & ~31;
+    if (Kp > 512) return seeme_fail("linear_h: K > 512 not supported");
+    if (a.ln_w && a.N != 256) return seeme_fail("linear_h: fused LayerNorm needs N == 256");
+    const size_t lds = (size_t)(TILE_M * (Kp + LDS_PAD) + TILE_M * (CH_N + LDS_PAD)) * 4 + (size_t)TILE_M * (Kp + HPAD) * 2;
+    dim3 grid((a.M + TILE_M - 1) / TILE_M, (a.N + CH_N - 1) / CH_N);
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_linear_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_linear_h, grid, dim3(256), lds, st, ha);
+    return seeme_check_launch("k_linear_h");
+}
+
+// ---------------------------------------------------------------------------------------------
+struct AttnHArgs {
+    const unsigned short* qk;     // [B*S][512] fp16 q | k
+    const unsigned short* vt;     // [B][256][spv] fp16 V^T (zero beyond S)
+    const float* res; const uint4* wo; const float* bo; const float* ln_w; const float* ln_b;
+    float* out; const int32_t* lengths;
+    int S, n_prefix, q_rows, Sp, spv;
+    float scale, eps;
+};
+
+__global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
+    const int ldp = a.Sp + LDS_PAD, ldq = 256 + HPAD, ldph = a.Sp + HPAD;
+    float* Ps = smem;                                                       // [32][Sp+8] fp32 scores, later the out_proj tile
+    unsigned short* Qh = reinterpret_cast<unsigned short*>(Ps + TILE_M * ldp);   // [32][272] Q, later O
+    unsigned short* Ph = Qh + TILE_M * ldq;                                 // [32][Sp+16] probabilities
+    int b = blockIdx.y, qt = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {    // all query tiles of one sequence on one XCD (speed only)
+        const int L = blockIdx.x + gridDim.x * blockIdx.y, rr = L & 7, q = L >> 3;
+        b = rr + 8 * (q / (int)gridDim.x);
+        qt = q % (int)gridDim.x;
+    }
+    const int q0 = qt * TILE_M;
+    const size_t base = (size_t)b * a.S;
+    const int n_valid_keys = min(a.S, a.n_prefix + a.lengths[b]);
+
+    for (int idx = tid; idx < TILE_M * 32; idx += 256) {       // Q tile, 8 halves per thread
+        const int row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (s < a.q_rows) v = *reinterpret_cast<const uint4*>(a.qk + (base + s) * 512 + c8);
+        *reinterpret_cast<uint4*>(Qh + row * ldq + c8) = v;
+    }
+    __syncthreads();
+    const unsigned short* Kmat = a.qk + base * 512 + 256;
+    for (int c0 = 0; c0 < a.Sp; c0 += CH_N) {
+        const int n0 = c0 + wave * 64;
+        f32x4 acc[2][4];
+        acc_zero(acc);
+        if (n0 < a.S) gemm_rows<2, 4>(Qh, ldq, Kmat, 512, n0, a.S, 8, acc);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int c = n0 + nt * 16 + r;
+            const bool ok = c < n_valid_keys;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Ps[(mt * 16 + 4 * kq + i) * ldp + c] = ok ? acc[mt][nt][i] * a.scale : -INFINITY;
+        }
+    }
+    __syncthreads();
+    for (int rr = 0; rr < 8; ++rr) {                           // softmax (fp32) -> fp16 probabilities
+        const float* prow = Ps + (wave * 8 + rr) * ldp;
+        unsigned short* hrow = Ph + (wave * 8 + rr) * ldph;
+        float mx = -INFINITY;
+        for (int c = lane; c < a.Sp; c += 64) mx = fmaxf(mx, prow[c]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int c = lane; c < a.Sp; c += 64) sum += expf(prow[c] - mx);
+        const float inv = 1.f / wave_sum(sum);
+        for (int c = lane; c < a.Sp; c += 64) hrow[c] = f2h(expf(prow[c] - mx) * inv);
+    }
+    __syncthreads();
+    {   // O = P V : contraction over keys, V^T rows are the B operand
+        f32x4 acc[2][4];
+        acc_zero(acc);
+        const int K32 = (n_valid_keys + 31) >> 5;
+        gemm_rows<2, 4>(Ph, ldph, a.vt + (size_t)b * 256 * a.spv, a.spv, wave * 64, 256, K32, acc);
+        acc_store_h16<2, 4>(acc, Qh, ldq, wave * 64, nullptr, SEEME_ACT_NONE);
+    }
+    __syncthreads();
+    float* Cs = Ps;
+    const int ldc = 256 + LDS_PAD;
+    {
+        f32x4 acc[2][4];
+        acc_zero(acc);
+        gemm_packed<2, 4>(Qh, ldq, a.wo, 8, wave * 4, 16, 8, acc);
+        acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, a.bo, 0, 256, SEEME_ACT_NONE);
+    }
+    __syncthreads();
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr, s = q0 + row;
+        if (s >= a.q_rows) continue;
+        const size_t g = (base + s) * 256 + lane * 4;
+        float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + lane * 4);
+        const float4 x = *reinterpret_cast<const float4*>(a.res + g);
+        v = make_float4(v.x + x.x, v.y + x.y, v.z + x.z, v.w + x.w);
+        v = wave_layernorm256(v, a.ln_w, a.ln_b, a.eps);
+        *reinterpret_cast<float4*>(a.out + g) = v;
+    }
+}
+
+static int launch_attn_h(const AttnHArgs& a_in, int B, hipStream_t st) {
+    AttnHArgs a = a_in;
+    if (a.S <= 0 || a.S > 512) return seeme_fail("attention_h: S must be in 1..512");
+    a.Sp = (a.S + CH_N - 1) / CH_N * CH_N;
+    const size_t lds = (size_t)TILE_M * (a.Sp + LDS_PAD) * 4 + (size_t)TILE_M * (256 + HPAD) * 2 + (size_t)TILE_M * (a.Sp + HPAD) * 2;
+    dim3 grid((a.q_rows + TILE_M - 1) / TILE_M, B);
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_attn_block_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_attn_block_h, grid, dim3(256), lds, st, a);
+    return seeme_check_launch("k_attn_block_h");
+}
+
+// ---------------------------------------------------------------------------------------------
+struct FfnHArgs {
+    const float* x; float* out;
+    const uint4* w1; const float* b1; const uint4* w2; const float* b2;
+    const float* ln_w; const float* ln_b;
+    const float* cvec; int cvec_ld; const float* lnc_w; const float* lnc_b;
+    const float* fin_w; const float* fin_b;
+    int M, FF, act, seq_rows, seq_stride, out_mode;
+    float eps;
+};
+
+__global__ __launch_bounds__(256) void k_ffn_block_h(const FfnHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ld = 256 + LDS_PAD, ldh = 256 + HPAD;
+    float* Xs = smem;                                                      // [32][264] fp32 block input (residual)
+    float* Cs = Xs + TILE_M * ld;                                          // [32][264] fp32 output tile
+    unsigned short* Xh = reinterpret_cast<unsigned short*>(Cs + TILE_M * ld);   // [32][272] fp16 A operand
+    unsigned short* Hh = Xh + TILE_M * ldh;                                // [32][FF+16] hidden (FF = 128)
+    const int m0 = blockIdx.x * TILE_M;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr, m = m0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < a.M) {
+            const int seq = m / a.seq_rows;
+            const size_t prow = (size_t)seq * a.seq_stride + (m % a.seq_rows);
+            v = *reinterpret_cast<const float4*>(a.x + prow * 256 + lane * 4);
+            if (a.cvec != nullptr) {
+                const float4 c = *reinterpret_cast<const float4*>(a.cvec + (size_t)seq * a.cvec_ld + lane * 4);
+                v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
+                v = wave_layernorm256(v, a.lnc_w, a.lnc_b, a.eps);
+            }
+        }
+        *reinterpret_cast<float4*>(Xs + row * ld + lane * 4) = v;
+        const unsigned lo = (unsigned)f2h(v.x) | ((unsigned)f2h(v.y) << 16), hi = (unsigned)f2h(v.z) | ((unsigned)f2h(v.w) << 16);
+        *reinterpret_cast<uint2*>(Xh + row * ldh + lane * 4) = make_uint2(lo, hi);
+    }
+    __syncthreads();
+    const int ldhh = a.FF + HPAD;
+    {   // hidden = act(W1 x + b1): FF = 128 -> 32 columns per wave
+        f32x4 acc1[2][2];
+        acc_zero(acc1);
+        gemm_packed<2, 2>(Xh, ldh, a.w1, 8, wave * 2, a.FF >> 4, 8, acc1);
+        acc_store_h16<2, 2>(acc1, Hh, ldhh, wave * 32, a.b1, a.act);
+    }
+    __syncthreads();
+    {
+        f32x4 acc2[2][4];
+        acc_zero(acc2);
+        gemm_packed<2, 4>(Hh, ldhh, a.w2, a.FF >> 5, wave * 4, 16, a.FF >> 5, acc2);
+        acc_store_lds<2, 4>(acc2, Cs, ld, wave * 64, a.b2, 0, 256, SEEME_ACT_NONE);
+    }
+    __syncthreads();
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr, m = m0 + row;
+        if (m >= a.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(Cs + row * ld + lane * 4);
+        const float4 x = *reinterpret_cast<const float4*>(Xs + row * ld + lane * 4);
+        v = make_float4(v.x + x.x, v.y + x.y, v.z + x.z, v.w + x.w);
+        v = wave_layernorm256(v, a.ln_w, a.ln_b, a.eps);
+        if (a.fin_w != nullptr) v = wave_layernorm256(v, a.fin_w, a.fin_b, a.eps);
+        const int seq = m / a.seq_rows, sr = m % a.seq_rows;
+        size_t orow = (size_t)seq * a.seq_stride + sr;
+        if (a.out_mode == 1) orow = (size_t)sr * (a.M / a.seq_rows) + seq;
+        *reinterpret_cast<float4*>(a.out + orow * 256 + lane * 4) = v;
+    }
+}
+
+static int launch_ffn_h(const FfnHArgs& a, hipStream_t st) {
+    if (a.FF != 128) return seeme_fail("ffn_h: FF must be 128 (hard-coded in the reference VAE, mld_vae.py:53)");
+    const size_t lds = (size_t)2 * TILE_M * (256 + LDS_PAD) * 4 + (size_t)TILE_M * (256 + HPAD) * 2 + (size_t)TILE_M * (a.FF + HPAD) * 2;
+    dim3 grid((a.M + TILE_M - 1) / TILE_M);
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_ffn_block_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_ffn_block_h, grid, dim3(256), lds, st, a);
+    return seeme_check_launch("k_ffn_block_h");
+}
+
+// ---------------------------------------------------------------------------------------------
+// host sequencing (mirrors vae_kernels.hip)
+__global__ void k_enc_tokens_h(const float* __restrict__ token, const float* __restrict__ pe, float* __restrict__ x, int B, int S) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * 2 * 256) return;
+    const int d = idx & 255, i = (idx >> 8) & 1, b = idx >> 9;
+    x[((size_t)b * S + i) * 256 + d] = token[i * 256 + d] + pe[i * 256 + d];
+}
+__global__ void k_bcast_rows_h(const float* __restrict__ src, float* __restrict__ dst, int B, int rows) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)rows * 64;
+    if (idx >= per * B) return;
+    reinterpret_cast<float4*>(dst)[idx] = reinterpret_cast<const float4*>(src)[idx % per];
+}
+
+struct WsH { float *x, *y, *sk0, *sk1, *cvec; unsigned short *qk, *vt; int spv; };
+static WsH carve_h(void* ws, int B, int S) {
+    const size_t R = (size_t)B * S;
+    float* p = (float*)ws;
+    WsH w;
+    w.x = p; p += R * 256; w.y = p; p += R * 256; w.sk0 = p; p += R * 256; w.sk1 = p; p += R * 256;
+    unsigned short* h = (unsigned short*)p;          // the fp32 path's qkv region [R][768] floats
+    w.qk = h; h += R * 512;
+    w.spv = (S + 31) & ~31;
+    w.vt = h;                                        // B*256*spv halves <= R*1024 halves
+    p += R * 768;
+    w.cvec = p;
+    return w;
+}
+
+static int lin_h(hipStream_t st, const float* A, int lda, const uint16_t* wp, int K, int N, const float* bias, float* Y, int ldy,
+                 int M, const float* pre_ln_w = nullptr, const float* pre_ln_b = nullptr) {
+    LinearHArgs ha{};
+    ha.k.a.A = A; ha.k.a.lda = lda; ha.k.a.K1 = K; ha.k.a.K = K; ha.k.a.bias = bias; ha.k.a.Y = Y; ha.k.a.ldy = ldy;
+    ha.k.a.M = M; ha.k.a.N = N; ha.k.a.eps = 1e-5f; ha.k.a.pre_ln_w = pre_ln_w; ha.k.a.pre_ln_b = pre_ln_b;
+    ha.wp = (const uint4*)wp; ha.kstride = ((K + 31) & ~31) >> 5; ha.ntiles = (N + 15) >> 4;
+    return launch_linear_h(ha, st);
+}
+
+static int run_layer_h(hipStream_t st, const SeemeXfLayer& L, const SeemeXfLayerH& H, float* cur, float* mid, float* out, WsH& ws,
+                       const int32_t* lengths, int B, int S, int n_prefix, int q_rows, const float* cvec, int cvec_ld,
+                       const float* fin_w, const float* fin_b, int out_mode) {
+    LinearHArgs q{};
+    q.k.a.A = cur; q.k.a.lda = 256; q.k.a.K1 = 256; q.k.a.K = 256; q.k.a.bias = L.in_b; q.k.a.M = B * S; q.k.a.N = 768; q.k.a.eps = 1e-5f;
+    q.wp = (const uint4*)H.in_w; q.kstride = 8; q.ntiles = 48; q.qkv_mode = 1; q.qk = ws.qk; q.vt = ws.vt; q.S = S; q.spv = ws.spv;
+    int rc = launch_linear_h(q, st);
+    if (rc) return rc;
+    AttnHArgs at{};
+    at.qk = ws.qk; at.vt = ws.vt; at.res = cur; at.wo = (const uint4*)H.out_w; at.bo = L.out_b; at.ln_w = L.n1_w; at.ln_b = L.n1_b;
+    at.out = mid; at.lengths = lengths; at.S = S; at.n_prefix = n_prefix; at.q_rows = q_rows; at.spv = ws.spv;
+    at.scale = 1.0f / 16.0f; at.eps = 1e-5f;
+    if ((rc = launch_attn_h(at, B, st))) return rc;
+    FfnHArgs f{};
+    f.x = mid; f.out = out; f.w1 = (const uint4*)H.l1_w; f.b1 = L.l1_b; f.w2 = (const uint4*)H.l2_w; f.b2 = L.l2_b;
+    f.M = B * q_rows; f.FF = 128; f.act = SEEME_ACT_GELU; f.seq_rows = q_rows; f.seq_stride = S; f.out_mode = out_mode; f.eps = 1e-5f;
+    f.fin_w = fin_w; f.fin_b = fin_b;
+    if (cvec != nullptr) { f.cvec = cvec; f.cvec_ld = cvec_ld; f.lnc_w = L.n2_w; f.lnc_b = L.n2_b; f.ln_w = L.n3_w; f.ln_b = L.n3_b; }
+    else { f.ln_w = L.n2_w; f.ln_b = L.n2_b; }
+    return launch_ffn_h(f, st);
+}
+
+static int skip_lin_h(hipStream_t st, const float* a1, const float* a2, const uint16_t* wp, const float* b, float* y, int M) {
+    LinearHArgs ha{};
+    ha.k.a.A = a1; ha.k.a.lda = 256; ha.k.a.A2 = a2; ha.k.a.lda2 = 256; ha.k.a.K1 = 256; ha.k.a.K = 512; ha.k.a.bias = b;
+    ha.k.a.Y = y; ha.k.a.ldy = 256; ha.k.a.M = M; ha.k.a.N = 256; ha.k.a.eps = 1e-5f;
+    ha.wp = (const uint4*)wp; ha.kstride = 16; ha.ntiles = 16;
+    return launch_linear_h(ha, st);
+}
+
+int seeme_vae_encode_h16(const SeemeVaeWeights* w, const float* features, const int32_t* lengths, int B, int T, float* mu,
+                         void* workspace, hipStream_t st) {
+    const SeemeVaeWeightsH* H = w->h16;
+    const int S = T + 2, F = w->nfeats;
+    WsH ws = carve_h(workspace, B, S);
+    const SeemeSkipStack& E = w->enc;
+    SEEME_HIP(hipMemsetAsync(ws.vt, 0, (size_t)B * 256 * ws.spv * 2, st));
+    hipLaunchKernelGGL(k_enc_tokens_h, dim3((B * 512 + 255) / 256), dim3(256), 0, st, w->token, w->pe_enc, ws.x, B, S);
+    int rc = seeme_check_launch("k_enc_tokens_h");
+    if (rc) return rc;
+    {
+        LinearHArgs ha{};
+        ha.k.a.A = features; ha.k.a.lda = F; ha.k.a.K1 = F; ha.k.a.K = F; ha.k.a.bias = w->emb_b; ha.k.a.res = w->pe_enc; ha.k.a.ldr = 256;
+        ha.k.a.Y = ws.x; ha.k.a.ldy = 256; ha.k.a.M = B * T; ha.k.a.N = 256; ha.k.a.eps = 1e-5f;
+        ha.k.seq_in = T; ha.k.in_stride = T; ha.k.out_stride = S; ha.k.out_off = 2; ha.k.res_mode = 1; ha.k.res_off = 2;
+        ha.wp = (const uint4*)H->emb_w; ha.kstride = ((F + 31) & ~31) >> 5; ha.ntiles = 16;
+        if ((rc = launch_linear_h(ha, st))) return rc;
+    }
+    if ((rc = run_layer_h(st, E.layer[0], H->enc[0], ws.x, ws.y, ws.sk0, ws, lengths, B, S, 2, S, nullptr, 0, nullptr, nullptr, 0))) return rc;
+    if ((rc = run_layer_h(st, E.layer[1], H->enc[1], ws.sk0, ws.y, ws.sk1, ws, lengths, B, S, 2, S, nullptr, 0, nullptr, nullptr, 0))) return rc;
+    if ((rc = run_layer_h(st, E.layer[2], H->enc[2], ws.sk1, ws.y, ws.x, ws, lengths, B, S, 2, S, nullptr, 0, nullptr, nullptr, 0))) return rc;
+    if ((rc = skip_lin_h(st, ws.x, ws.sk1, H->enc_skip[0], E.skip_b[0], ws.x, B * S))) return rc;
+    if ((rc = run_layer_h(st, E.layer[3], H->enc[3], ws.x, ws.y, ws.x, ws, lengths, B, S, 2, S, nullptr, 0, nullptr, nullptr, 0))) return rc;
+    if ((rc = skip_lin_h(st, ws.x, ws.sk0, H->enc_skip[1], E.skip_b[1], ws.x, B * S))) return rc;
+    return run_layer_h(st, E.layer[4], H->enc[4], ws.x, ws.y, mu, ws, lengths, B, S, 2, 2, nullptr, 0, E.norm_w, E.norm_b, 1);
+}
+
+int seeme_vae_decode_h16(const SeemeVaeWeights* w, const float* z, const int32_t* lengths, int B, int T, float* feats,
+                         void* workspace, hipStream_t st) {
+    const SeemeVaeWeightsH* H = w->h16;
+    const int S = T, F = w->nfeats;
+    WsH ws = carve_h(workspace, B, S + 2);
+    ws.spv = (S + 31) & ~31;
+    const SeemeSkipStack& Dk = w->dec;
+    int rc;
+    SEEME_HIP(hipMemsetAsync(ws.vt, 0, (size_t)B * 256 * ws.spv * 2, st));
+    const int CL = SEEME_NLAYERS * 256;
+    if ((rc = lin_h(st, z, 256, H->ca_fold_w, 256, CL, w->ca_fold_b, ws.cvec, CL, B))) return rc;
+    {
+        const size_t n4 = (size_t)B * S * 64;
+        hipLaunchKernelGGL(k_bcast_rows_h, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w->pe_dec, ws.x, B, S);
+        if ((rc = seeme_check_launch("k_bcast_rows_h"))) return rc;
+    }
+    if ((rc = run_layer_h(st, Dk.layer[0], H->dec[0], ws.x, ws.y, ws.sk0, ws, lengths, B, S, 0, S, ws.cvec + 0 * 256, CL, nullptr, nullptr, 0))) return rc;
+    if ((rc = run_layer_h(st, Dk.layer[1], H->dec[1], ws.sk0, ws.y, ws.sk1, ws, lengths, B, S, 0, S, ws.cvec + 1 * 256, CL, nullptr, nullptr, 0))) return rc;
+    if ((rc = run_layer_h(st, Dk.layer[2], H->dec[2], ws.sk1, ws.y, ws.x, ws, lengths, B, S, 0, S, ws.cvec + 2 * 256, CL, nullptr, nullptr, 0))) return rc;
+    if ((rc = skip_lin_h(st, ws.x, ws.sk1, H->dec_skip[0], Dk.skip_b[0], ws.x, B * S))) return rc;
+    if ((rc = run_layer_h(st, Dk.layer[3], H->dec[3], ws.x, ws.y, ws.x, ws, lengths, B, S, 0, S, ws.cvec + 3 * 256, CL, nullptr, nullptr, 0))) return rc;
+    if ((rc = skip_lin_h(st, ws.x, ws.sk0, H->dec_skip[1], Dk.skip_b[1], ws.x, B * S))) return rc;
+    if ((rc = run_layer_h(st, Dk.layer[4], H->dec[4], ws.x, ws.y, ws.x, ws, lengths, B, S, 0, S, ws.cvec + 4 * 256, CL, nullptr, nullptr, 0))) return rc;
+    return lin_h(st, ws.x, 256, H->fin_w, 256, F, w->fin_b, feats, F, B * S, Dk.norm_w, Dk.norm_b);
+}

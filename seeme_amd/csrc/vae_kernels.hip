@@ -452,6 +452,7 @@ extern "C" int seeme_vae_encode(const SeemeVaeWeights* w, const float* features,
     if (mu + (size_t)B * 256 != logvar) return seeme_fail("vae_encode: mu/logvar must be one [2,B,256] buffer");
     const int S = T + 2, F = w->nfeats;
     if (ws_bytes < seeme_vae_workspace_bytes(B, T)) return seeme_fail("vae_encode: workspace too small");
+    if (w->h16 != nullptr) return seeme_vae_encode_h16(w, features, lengths, B, T, mu, workspace, st);
     VaeWs ws = carve(workspace, B, S);
     const SeemeSkipStack& E = w->enc;
 
@@ -487,6 +488,7 @@ extern "C" int seeme_vae_decode(const SeemeVaeWeights* w, const float* z, const 
     if (B <= 0 || T <= 0 || T > 500) return seeme_fail("vae_decode: need B>0 and 0 < T <= 500");
     if (ws_bytes < seeme_vae_workspace_bytes(B, T)) return seeme_fail("vae_decode: workspace too small");
     const int S = T, F = w->nfeats;
+    if (w->h16 != nullptr) return seeme_vae_decode_h16(w, z, lengths, B, T, feats, workspace, st);
     VaeWs ws = carve(workspace, B, S + 2);
     const SeemeSkipStack& Dk = w->dec;
     int rc;

@@ -96,8 +96,12 @@ class MldVae(nn.Module):
                  normalize_before: bool = False,
                  activation: str = "gelu",
                  position_embedding: str = "learned",
+                 precision: str = "fp32",
                  **kwargs) -> None:
         super().__init__()
+        if precision not in ("fp32", "fp16"):
+            raise ValueError("precision must be 'fp32' (fp32-exact MFMA, parity path) or 'fp16' (fp16 MFMA operands)")
+        self.precision = precision
         # The reference overrides the configured sizes (mld_vae.py:51-53); checkpoints depend on it.
         num_layers, num_heads, ff_size = 5, 1, 128
         self.latent_size = latent_dim[0]
@@ -136,7 +140,7 @@ class MldVae(nn.Module):
 
     # ------------------------------------------------------------------ weight image
     def _weights(self) -> L.VaeWeights:
-        fpnt = _param_fingerprint(self)
+        fpnt = (_param_fingerprint(self), self.precision)
         if self._wcache is not None and self._wcache[0] == fpnt:
             return self._wcache[1]
         for p in self.parameters():
@@ -185,6 +189,20 @@ class MldVae(nn.Module):
             fold_w, fold_b = torch.cat(fw).contiguous(), torch.cat(fb).contiguous()
         keep += [fold_w, fold_b]
         w.ca_fold_w, w.ca_fold_b = fold_w.data_ptr(), fold_b.data_ptr()
+        w.h16 = 0
+        if self.precision == "fp16":
+            h = L.VaeWeightsH()
+            pk = lambda W: (keep.append(L.pack_mfma16(W, torch.float16)), keep[-1].data_ptr())[1]
+            for stack, dst in ((self.encoder, h.enc), (self.decoder, h.dec)):
+                for i, blk in enumerate(stack.blocks()):
+                    dst[i].in_w, dst[i].out_w = pk(blk.self_attn.in_proj_weight), pk(blk.self_attn.out_proj.weight)
+                    dst[i].l1_w, dst[i].l2_w = pk(blk.linear1.weight), pk(blk.linear2.weight)
+            for i in range(2):
+                h.enc_skip[i] = pk(self.encoder.linear_blocks[i].weight)
+                h.dec_skip[i] = pk(self.decoder.linear_blocks[i].weight)
+            h.emb_w, h.fin_w, h.ca_fold_w = pk(self.skel_embedding.weight), pk(self.final_layer.weight), pk(fold_w)
+            keep.append(h)
+            w.h16 = C.addressof(h)
         self._wcache = (fpnt, w, keep)
         return w
 

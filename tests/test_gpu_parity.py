@@ -457,3 +457,19 @@ def test_pointnet_bf16_vs_fp32(dev):
     assert e < 3e-2
     P = recipe_state_dict(shapes.pointnet_shapes())
     assert rel_err(got.cpu().numpy(), O.pointnet_forward(P, pts.cpu().numpy())) < 3e-2
+
+
+def test_vae_fp16_mfma_mode(dev):
+    """Throughput mode of the VAE (fp16 MFMA operands, fp32 accumulation and residual stream): measured against the
+    reference fixtures; bound 2e-2 of the output range (reported, not the 1e-4 parity gate)."""
+    from seeme_amd.mld_vae import MldVae
+    for name, F in (("vae_F132_T24.npz", 132), ("vae_F75_T60.npz", 75), ("vae_F132_T196.npz", 132)):
+        g = load_golden(name)
+        vae = load_recipe_(MldVae(ablation(), nfeats=F, latent_dim=[1, 256], arch="encoder_decoder", precision="fp16")).to(dev).eval()
+        lengths = g["lengths"].tolist()
+        _, dist = vae.encode(torch.from_numpy(g["features"]).to(dev), None, lengths)
+        e_mu = rel_err(dist.loc.cpu().numpy(), g["mu"])
+        dec = vae.decode(torch.from_numpy(g["mu"]).to(dev), lengths)
+        e_dec = rel_err(dec.cpu().numpy(), g["decoded"])
+        print(f"fp16-MFMA VAE {name}: mu rel err {e_mu:.3e}, decode rel err {e_dec:.3e}")
+        assert e_mu < 2e-2 and e_dec < 2e-2
