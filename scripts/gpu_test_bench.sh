@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q -s > gpurun_out/tests.log 2>&1; grep -E "rel err|MPJPE|passed|failed|Error" gpurun_out/tests.log | tail -12
+true
 python bench.py --steps 10 --warmup 2 --weights fp32 --vae fp32 --no-cpu-baseline > gpurun_out/bench_fp32.json 2> gpurun_out/bench_fp32.err
 python bench.py --steps 10 --warmup 2 --weights bf16 --vae fp32 --no-cpu-baseline > gpurun_out/bench_bf16.json 2> gpurun_out/bench_bf16.err
 python bench.py --steps 10 --warmup 2 --weights fp16 --vae fp16 --no-cpu-baseline > gpurun_out/bench_fp16.json 2> gpurun_out/bench_fp16.err
