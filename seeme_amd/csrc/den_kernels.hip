@@ -15,13 +15,13 @@
 #include "common.hpp"
 #include "api_util.hpp"
 #include "den_layout.h"
+#include "lds_ring.hpp"
 #include <utility>
 
 #define DEN_THREADS 512
 #define DEN_MAXTOK 6   // 1 latent + N<=4 condition tokens + 1 time token
-#ifndef DEN_CHMAX
-#define DEN_CHMAX 8    // 16-B vectors per lane per chunk (two chunks in flight: 2 x 8 x 4 = 64 VGPRs)
-#endif
+#define DEN_R 4        // register ring: chunks of the weight stream in flight per lane
+#define DEN_CH 8       // 16-B vectors per lane per chunk (ring = 4 x 8 x 4 = 128 VGPRs)
 
 // ------------------------------------------------------------------ weight element types
 struct WF32 { typedef float T; static constexpr int KV = 4; static constexpr bool HALF = false; };      // 16-B vector = 4 weights
@@ -31,184 +31,252 @@ struct WF16 { typedef uint16_t T; static constexpr int KV = 8; static constexpr 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// One chunk of this thread's weight stream: up to DEN_CHMAX x 16 B per lane.
-struct WBuf { u32x4 r[DEN_CHMAX]; };
-// Where the NEXT GEMV's first chunk of this thread lives (weights do not depend on activations, so
-// it is requested before the current GEMV's epilogue and lands while the reductions/barriers run).
-// Addresses are buffer-load style: per-thread byte offset (VGPR) + wave-uniform byte offset (SGPR),
-// so no 64-bit per-chunk pointers are kept in vector registers.
-struct NextPre { unsigned voff; unsigned soff; int stride; int ch; };
+struct Ring { u32x4 r[DEN_R][DEN_CH]; };
 
-// GEMV work split over the 512 threads.  A PyTorch [N,K] matrix is stored as [K/KV][N] 16-B vectors;
-// an "item" = (k-slice ks, output n); thread tid owns items tid, tid+512, ...
-template <typename WT, int K, int N>
-struct GemvShape {
-    static constexpr int KS = (N >= 512) ? ((N % 512 == 0) ? 1 : 2) : (512 / N);   // k-slices
-    static constexpr int NQ = K / WT::KV / KS;                                      // vectors per item
-    static constexpr int CH = (NQ / 2 < DEN_CHMAX) ? (NQ / 2) : DEN_CHMAX;                       // vectors per chunk
-    static constexpr int CPI = NQ / CH;                                             // chunks per item
-    static constexpr int IT = N * KS / DEN_THREADS;                                 // items per thread
+#define FF_SA 1024   // sa_block feed-forward, hard-coded in the reference (mdiff_transformer.py:279)
+#define FF_D 128     // ffn_dim (configs/modules/denoiser.yaml:5)
+#define XB_LD 1024   // row stride of the GEMV input buffer
+
+// ------------------------------------------------------------------ the static weight-stream program
+// GEMV ids = index of the matrix offset inside DenLayerOff (den_layout.h).
+enum { G_SKIP = 0, G_INP, G_OUTP, G_L1, G_L2, G_CAQ, G_CAO, G_F1, G_F2, G_FO, G_NUM };
+constexpr int den_gK(int g) { constexpr int k[G_NUM] = {512, 256, 256, 256, FF_SA, 256, 256, 256, FF_D, 256}; return k[g]; }
+constexpr int den_gN(int g) { constexpr int n[G_NUM] = {256, 768, 256, FF_SA, 256, 256, 256, FF_D, 256, 256}; return n[g]; }
+
+// GEMV work split over the 512 threads.  A PyTorch [N,K] matrix is stored as [K/KV][N] 16-B vectors.  An
+// "item" = (k-slice ks, output pair n0 / n0 + N/2); thread tid owns items tid, tid+512, ...  Both outputs of
+// an item read the same input values, so every LDS read of x feeds two weight vectors.  An item is streamed
+// in chunks of 4 k-vectors x 2 outputs = DEN_CH coalesced 16-B loads per lane, 64 KiB per workgroup.
+constexpr int den_gcd(int a, int b) { return b == 0 ? a : den_gcd(b, a % b); }
+template <typename WT, int G>
+struct GS {
+    static constexpr int K = den_gK(G), N = den_gN(G);
+    static constexpr int G0 = N / 2;                                                // output pairs
+    static constexpr int KS = DEN_THREADS / den_gcd(G0, DEN_THREADS);               // k-slices
+    static constexpr int IT = G0 / den_gcd(G0, DEN_THREADS);                        // items per thread
+    static constexpr int NQ = K / WT::KV / KS;                                      // k-vectors per item
+    static constexpr int CPI = NQ / 4;                                              // chunks per item
     static constexpr int TOT = IT * CPI;                                            // chunks per thread
-    static_assert(N * KS % DEN_THREADS == 0 && NQ % CH == 0 && TOT % 2 == 0 && CH >= 1, "unsupported GEMV shape");
-    // per-thread byte offset of item `it` (vector (ks*NQ)*N + n)
-    __device__ static __forceinline__ unsigned item_voff(int tid, int it) {
+    static_assert(G0 * KS == DEN_THREADS * IT && NQ * KS * WT::KV == K && NQ % 4 == 0 && TOT >= 1, "unsupported GEMV shape");
+    __device__ static __forceinline__ void item(int tid, int it, int& ks, int& n0) {
         const int idx = tid + it * DEN_THREADS;
-        const int ks = idx / N, n = idx - ks * N;
-        return (unsigned)(ks * NQ * N + n) * 16u;
-    }
-    // wave-uniform byte offset of chunk c of an item, relative to the matrix start
-    static constexpr unsigned chunk_soff(int c) { return (unsigned)(c * CH) * N * 16u; }
-    __device__ static __forceinline__ NextPre pre(int tid, long long w_elem_off) {
-        return NextPre{item_voff(tid, 0), (unsigned)(w_elem_off * (long long)sizeof(typename WT::T)), N * 16, CH};
+        ks = idx / G0; n0 = idx - ks * G0;
     }
 };
 
-__device__ __forceinline__ void issue_rt(WBuf& b, __amdgpu_buffer_rsrc_t rsrc, const NextPre np) {
-#pragma unroll
-    for (int i = 0; i < DEN_CHMAX; ++i)
-        if (i < np.ch) b.r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, np.voff, np.soff + (unsigned)(i * np.stride), 0);
-}
-template <int CH>
-__device__ __forceinline__ void issue_n(WBuf& b, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, int stride) {
+// One layer streams P0 = inp, outp, l1, l2, [caq,] cao, f1, f2, fo (chunk indices 0 .. SUM-1, padded with
+// no-op chunks to a multiple of the ring size so that chunk t always lives in ring slot t % DEN_R);
+// layers 3 and 4 stream the skip linear first (its chunk count is a multiple of DEN_R too).
+template <typename WT, bool CAQ>
+struct Prog {
+    static constexpr int NG = CAQ ? 9 : 8;
+    static constexpr int gid(int i) {
+        constexpr int a[9] = {G_INP, G_OUTP, G_L1, G_L2, G_CAQ, G_CAO, G_F1, G_F2, G_FO};
+        constexpr int b[9] = {G_INP, G_OUTP, G_L1, G_L2, G_CAO, G_F1, G_F2, G_FO, G_FO};
+        return CAQ ? a[i] : b[i];
+    }
+    static constexpr int tot(int g) {
+        switch (g) {
+            case G_SKIP: return GS<WT, G_SKIP>::TOT; case G_INP: return GS<WT, G_INP>::TOT; case G_OUTP: return GS<WT, G_OUTP>::TOT;
+            case G_L1: return GS<WT, G_L1>::TOT; case G_L2: return GS<WT, G_L2>::TOT; case G_CAQ: return GS<WT, G_CAQ>::TOT;
+            case G_CAO: return GS<WT, G_CAO>::TOT; case G_F1: return GS<WT, G_F1>::TOT; case G_F2: return GS<WT, G_F2>::TOT;
+            default: return GS<WT, G_FO>::TOT;
+        }
+    }
+    static constexpr int start(int i) { int s = 0; for (int j = 0; j < i; ++j) s += tot(gid(j)); return s; }
+    static constexpr int SUM = start(NG);
+    static constexpr int T = (SUM + DEN_R - 1) / DEN_R * DEN_R;
+    static constexpr int PAD = T - SUM;
+    static constexpr int TS = tot(G_SKIP);
+    static constexpr int find(int t) { int i = 0; while (i + 1 < NG && start(i + 1) <= t) ++i; return i; }
+    static constexpr int pos(int g) { int i = 0; while (gid(i) != g) ++i; return i; }   // position of GEMV g in P0
+    static_assert(TS % DEN_R == 0 && TS >= DEN_R, "skip linear must fill whole ring turns");
+    static_assert(tot(G_INP) >= DEN_R, "the first GEMV of a layer must cover the cross-layer prefetch");
+};
+
+// ---- issue: chunk C of matrix G (base = byte offset of the matrix in the image) -> ring slot
+template <typename WT, int G, int C>
+__device__ __forceinline__ void issue_mat(u32x4 (&slot)[DEN_CH], int tid, __amdgpu_buffer_rsrc_t rsrc, unsigned mat_bytes) {
 #ifdef DEN_DBG_NOLOAD   // timing probe: arithmetic and epilogues without the weight stream
     return;
 #endif
+    typedef GS<WT, G> S;
+    constexpr int it = C / S::CPI, cc = C % S::CPI;
+    int ks, n0;
+    S::item(tid, it, ks, n0);
+    const unsigned voff = (unsigned)(ks * S::NQ * S::N + n0) * 16u;
+    const unsigned soff = mat_bytes + (unsigned)(cc * 4) * S::N * 16u;
 #pragma unroll
-    for (int i = 0; i < CH; ++i) b.r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + (unsigned)(i * stride), 0);
+    for (int i = 0; i < DEN_CH; ++i)   // vector i = k-vector i/2, output half i%2
+        slot[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + (unsigned)(((i >> 1) * S::N + (i & 1) * S::G0) * 16), 0);
 }
-template <int CH, int STRIDE>
-__device__ __forceinline__ void issue_ct(WBuf& b, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-#ifdef DEN_DBG_NOLOAD
-    return;
-#endif
+// Byte offsets of one layer's matrices inside the packed image, plus the first matrix of the NEXT layer's
+// stream.  Read once per layer into scalar registers: the program-order pins below are memory clobbers, so
+// anything still addressed through the layout table would be re-loaded (a scalar-cache round trip) per chunk.
+struct MatOffs { unsigned m[G_NUM]; unsigned next; };
+template <typename WT>
+__device__ __forceinline__ MatOffs load_mat_offs(const DenLayerOff* __restrict__ L, const DenLayerOff* __restrict__ Ln, bool nskip) {
+    MatOffs o;
 #pragma unroll
-    for (int i = 0; i < CH; ++i) b.r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + (unsigned)(i * STRIDE), 0);
+    for (int g = 0; g < G_NUM; ++g) o.m[g] = (unsigned)(reinterpret_cast<const int64_t*>(L)[g] * (long long)sizeof(typename WT::T));
+    o.next = (unsigned)((nskip ? Ln->skip : Ln->inp) * (long long)sizeof(typename WT::T));
+    return o;
+}
+
+// chunk T of P0 of the current layer
+template <typename WT, bool CAQ, int T>
+__device__ __forceinline__ void issue_p0(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo) {
+    typedef Prog<WT, CAQ> P;
+    static_assert(T >= 0 && T < P::SUM, "chunk outside the layer program");
+    constexpr int i = P::find(T), g = P::gid(i), c = T - P::start(i);
+    issue_mat<WT, g, c>(ring.r[T % DEN_R], tid, rsrc, mo.m[g]);
+}
+// chunk T counted from the start of the current layer's P0; T >= P::T addresses the next layer, whose stream
+// starts with its skip linear when nskip is set and with in_proj otherwise (mo.next either way)
+template <typename WT, bool CAQ, int T>
+__device__ __forceinline__ void issue_rel(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip) {
+    typedef Prog<WT, CAQ> P;
+    if constexpr (T < P::SUM) {
+        issue_p0<WT, CAQ, T>(ring, tid, rsrc, mo);
+    } else if constexpr (T >= P::T) {
+        constexpr int j = T - P::T;
+        static_assert(j < DEN_R && j < GS<WT, G_INP>::TOT && j < P::TS, "prefetch reaches too far into the next layer");
+        if (nskip) issue_mat<WT, G_SKIP, j>(ring.r[j % DEN_R], tid, rsrc, mo.next);
+        else issue_mat<WT, G_INP, j>(ring.r[j % DEN_R], tid, rsrc, mo.next);
+    }   // else: padding chunk, nothing to load
 }
 
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
-// acc[s] += W-chunk . x[s][k0 ...]   (x in LDS, broadcast reads; packed fp32 FMAs)
-template <typename WT, int CH, int MS>
-__device__ __forceinline__ void consume(const WBuf& b, const float* __restrict__ x, int ldx, int k0, f2 (&acc)[MS][2]) {
+// acc[s][j] += W-chunk(output half j) . x[s][k0 ...]   (x in LDS, broadcast reads; packed fp32 FMAs)
+template <typename WT, int MS>
+__device__ __forceinline__ void consume(const u32x4 (&b)[DEN_CH], const float* __restrict__ x, int ldx, int k0, f2 (&acc)[MS][2][2]) {
 #ifdef DEN_DBG_NOFMA   // timing probe: keep the weight stream, drop the arithmetic (results are garbage)
 #pragma unroll
-    for (int i = 0; i < CH; ++i) acc[0][0].x += __uint_as_float(b.r[i].x ^ b.r[i].y ^ b.r[i].z ^ b.r[i].w);
+    for (int i = 0; i < DEN_CH; ++i) acc[0][0][0].x += __uint_as_float(b[i].x ^ b[i].y ^ b[i].z ^ b[i].w);
     return;
 #endif
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        const u32x4 u = b.r[i];
+    for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
         for (int s = 0; s < MS; ++s) {
-            const float* xp = x + s * ldx + k0 + WT::KV * i;
+            const float* xp = x + s * ldx + k0 + WT::KV * kk;
             const float4 x0 = *reinterpret_cast<const float4*>(xp);
-            if constexpr (WT::KV == 4) {
-                acc[s][0] += f2{__uint_as_float(u.x), __uint_as_float(u.y)} * f2{x0.x, x0.y};
-                acc[s][1] += f2{__uint_as_float(u.z), __uint_as_float(u.w)} * f2{x0.z, x0.w};
-            } else if constexpr (WT::HALF) {
-                // fp16 weights: v_fma_mix_f32 takes the half operand directly (no unpack instructions)
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                const float4 x1 = *reinterpret_cast<const float4*>(xp + 4);
-                const unsigned ux = u.x, uy = u.y, uz = u.z, uw = u.w;   // (bit_cast straight from a vector element picks element 0)
-                const h2 w0 = __builtin_bit_cast(h2, ux), w1 = __builtin_bit_cast(h2, uy), w2 = __builtin_bit_cast(h2, uz), w3 = __builtin_bit_cast(h2, uw);
-                acc[s][0].x = fmaf((float)w0.x, x0.x, acc[s][0].x); acc[s][0].y = fmaf((float)w0.y, x0.y, acc[s][0].y);
-                acc[s][1].x = fmaf((float)w1.x, x0.z, acc[s][1].x); acc[s][1].y = fmaf((float)w1.y, x0.w, acc[s][1].y);
-                acc[s][0].x = fmaf((float)w2.x, x1.x, acc[s][0].x); acc[s][0].y = fmaf((float)w2.y, x1.y, acc[s][0].y);
-                acc[s][1].x = fmaf((float)w3.x, x1.z, acc[s][1].x); acc[s][1].y = fmaf((float)w3.y, x1.w, acc[s][1].y);
-            } else {
-                const float4 x1 = *reinterpret_cast<const float4*>(xp + 4);
-                acc[s][0] += f2{bf_lo(u.x), bf_hi(u.x)} * f2{x0.x, x0.y};
-                acc[s][1] += f2{bf_lo(u.y), bf_hi(u.y)} * f2{x0.z, x0.w};
-                acc[s][0] += f2{bf_lo(u.z), bf_hi(u.z)} * f2{x1.x, x1.y};
-                acc[s][1] += f2{bf_lo(u.w), bf_hi(u.w)} * f2{x1.z, x1.w};
+            float4 x1 = x0;
+            if constexpr (WT::KV == 8) x1 = *reinterpret_cast<const float4*>(xp + 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u32x4 u = b[2 * kk + j];
+                f2 (&a)[2] = acc[s][j];
+                if constexpr (WT::KV == 4) {
+                    a[0] += f2{__uint_as_float(u.x), __uint_as_float(u.y)} * f2{x0.x, x0.y};
+                    a[1] += f2{__uint_as_float(u.z), __uint_as_float(u.w)} * f2{x0.z, x0.w};
+                } else if constexpr (WT::HALF) {
+                    // fp16 weights: v_fma_mix_f32 takes the half operand directly (no unpack instructions)
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const unsigned ux = u.x, uy = u.y, uz = u.z, uw = u.w;   // (bit_cast straight from a vector element picks element 0)
+                    const h2 w0 = __builtin_bit_cast(h2, ux), w1 = __builtin_bit_cast(h2, uy), w2 = __builtin_bit_cast(h2, uz), w3 = __builtin_bit_cast(h2, uw);
+                    a[0].x = fmaf((float)w0.x, x0.x, a[0].x); a[0].y = fmaf((float)w0.y, x0.y, a[0].y);
+                    a[1].x = fmaf((float)w1.x, x0.z, a[1].x); a[1].y = fmaf((float)w1.y, x0.w, a[1].y);
+                    a[0].x = fmaf((float)w2.x, x1.x, a[0].x); a[0].y = fmaf((float)w2.y, x1.y, a[0].y);
+                    a[1].x = fmaf((float)w3.x, x1.z, a[1].x); a[1].y = fmaf((float)w3.y, x1.w, a[1].y);
+                } else {
+                    a[0] += f2{bf_lo(u.x), bf_hi(u.x)} * f2{x0.x, x0.y};
+                    a[1] += f2{bf_lo(u.y), bf_hi(u.y)} * f2{x0.z, x0.w};
+                    a[0] += f2{bf_lo(u.z), bf_hi(u.z)} * f2{x1.x, x1.y};
+                    a[1] += f2{bf_lo(u.w), bf_hi(u.w)} * f2{x1.z, x1.w};
+                }
             }
         }
     }
 }
 
-// One pipeline step t of a GEMV.  Chunk t lives in A for even t and in B for odd t (TOT is even).
-// Two chunks are always in flight: on entry chunks 0 (A) and 1 (B) of THIS GEMV have already been
-// requested by the previous GEMV; step t consumes chunk t and re-fills its buffer with chunk t+2, or,
-// for the last two steps, with chunks 0 / 1 of the NEXT GEMV -- those land while the epilogue of
-// this GEMV runs, so the weight stream never drains at a GEMV boundary.
-template <typename WT, int K, int N, int MS, int NCH, int T>
-__device__ __forceinline__ void gemv_step(int tid, __amdgpu_buffer_rsrc_t rsrc, unsigned wbase, const float* __restrict__ x, int ldx,
-                                          WBuf& A, WBuf& B, const NextPre& next, float* __restrict__ part,
-                                          f2 (&acc)[MS][2]) {
-    typedef GemvShape<WT, K, N> G;
-    constexpr int it = T / G::CPI, c = T % G::CPI;
-    const int idx = tid + it * DEN_THREADS;
-    const int ks = idx / N, n = idx - ks * N;
-    if constexpr (c == 0) {
+// Pin the program order: the accumulators pass through a side-effecting asm with a memory clobber, so the
+// arithmetic that read a ring slot stays above and the loads that re-fill the slot stay below it (otherwise
+// the instruction selector hoists the re-fill into fresh registers and the ring silently doubles).
+template <int MS>
+__device__ __forceinline__ void pin_acc(f2 (&acc)[MS][2][2]) {
 #pragma unroll
-        for (int s = 0; s < MS; ++s) { acc[s][0] = f2{0.f, 0.f}; acc[s][1] = f2{0.f, 0.f}; }
-    }
-    WBuf& cur = (T & 1) ? B : A;
-    consume<WT, G::CH, MS>(cur, x, ldx, (ks * G::NQ + c * G::CH) * WT::KV, acc);
-    if constexpr (T + 2 < G::TOT) {
-        constexpr int it2 = (T + 2) / G::CPI, c2 = (T + 2) % G::CPI;
-        issue_ct<G::CH, N * 16>(cur, rsrc, G::item_voff(tid, it2), wbase + G::chunk_soff(c2));
-    } else if constexpr (T + 2 == G::TOT) {
-        issue_n<NCH>(cur, rsrc, next.voff, next.soff, next.stride);                                   // next GEMV, chunk 0 -> A
-    } else {
-        issue_n<NCH>(cur, rsrc, next.voff, next.soff + (unsigned)(NCH * next.stride), next.stride);   // next GEMV, chunk 1 -> B
-    }
-    if constexpr (c == G::CPI - 1) {
-#pragma unroll
-        for (int s = 0; s < MS; ++s) part[(ks * MS + s) * N + n] = (acc[s][0].x + acc[s][0].y) + (acc[s][1].x + acc[s][1].y);
-    }
-    // keep the machine scheduler from hoisting later chunks' loads above this point: the register
-    // budget is sized for exactly two chunks
+    for (int s = 0; s < MS; ++s)
+        asm volatile("" : "+v"(acc[s][0][0]), "+v"(acc[s][0][1]), "+v"(acc[s][1][0]), "+v"(acc[s][1][1]) :: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
-template <typename WT, int K, int N, int MS, int NCH, int... Ts>
-__device__ __forceinline__ void gemv_steps(int tid, __amdgpu_buffer_rsrc_t rsrc, unsigned wbase, const float* __restrict__ x, int ldx,
-                                           WBuf& A, WBuf& B, const NextPre& next, float* __restrict__ part,
-                                           f2 (&acc)[MS][2], std::integer_sequence<int, Ts...>) {
-    (gemv_step<WT, K, N, MS, NCH, Ts>(tid, rsrc, wbase, x, ldx, A, B, next, part, acc), ...);
-}
 
-// part[ks][s][n] = partial dot products of W x[s]; A/B hold this GEMV's chunks 0/1 on entry and the
-// NEXT GEMV's chunks 0/1 (in flight) on exit.  Ends with a barrier (partials visible).
-// w_elem_off: element offset of the matrix inside the packed image.
-template <typename WT, int K, int N, int MS, int NCH>
-__device__ __forceinline__ void gemv_run(int tid, __amdgpu_buffer_rsrc_t rsrc, long long w_elem_off, const float* __restrict__ x,
-                                         int ldx, WBuf& A, WBuf& B, const NextPre next, float* __restrict__ part) {
-    f2 acc[MS][2];
-    const unsigned wbase = (unsigned)(w_elem_off * (long long)sizeof(typename WT::T));
-    gemv_steps<WT, K, N, MS, NCH>(tid, rsrc, wbase, x, ldx, A, B, next, part, acc,
-                             std::make_integer_sequence<int, GemvShape<WT, K, N>::TOT>{});
-    __syncthreads();
+// One chunk step of a GEMV of the layer program.  REL0 = index of the GEMV's first chunk relative to the
+// layer's P0 (negative for the skip linear), C = local chunk, NC = chunks incl. padding.  Consuming chunk t
+// frees ring slot t % DEN_R, which is re-filled with chunk t + DEN_R -- at once, except for the last BURST
+// chunks of the GEMV, whose re-fill is withheld until the epilogue runs (gemv_stream).
+template <typename WT, bool CAQ, int G, int REL0, int C>
+__device__ __forceinline__ void refill(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip) {
+    constexpr int TGT = REL0 + C + DEN_R;
+    if constexpr (TGT < 0) issue_mat<WT, G_SKIP, TGT + Prog<WT, CAQ>::TS>(ring.r[((TGT % DEN_R) + DEN_R) % DEN_R], tid, rsrc, mo.m[G_SKIP]);
+    else issue_rel<WT, CAQ, TGT>(ring, tid, rsrc, mo, nskip);
 }
-
-// out[s][n] = act(sum_ks part + bias).  Ends with a barrier.
-template <typename WT, int K, int N, int MS>
-__device__ __forceinline__ void combine_lds(int tid, const float* __restrict__ part, const float* __restrict__ bias, int act,
-                                            float* __restrict__ out, int ldo) {
-    constexpr int KS = GemvShape<WT, K, N>::KS;
-    for (int idx = tid; idx < N * MS; idx += DEN_THREADS) {
-        const int s = idx / N, n = idx - s * N;
-        float v = bias[n];
+template <typename WT, bool CAQ, int MS, int G, int REL0, int NC, int BURST, int C>
+__device__ __forceinline__ void gemv_chunk(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip,
+                                           const float* __restrict__ x, float* __restrict__ part, f2 (&acc)[MS][2][2]) {
+    typedef GS<WT, G> S;
+    constexpr int SLOT = ((REL0 + C) % DEN_R + DEN_R) % DEN_R;
+    if constexpr (C < S::TOT) {
+        constexpr int it = C / S::CPI, cc = C % S::CPI;
+        int ks, n0;
+        S::item(tid, it, ks, n0);
+        if constexpr (cc == 0) {
 #pragma unroll
-        for (int k2 = 0; k2 < KS; ++k2) v += part[(k2 * MS + s) * N + n];
-        out[s * ldo + n] = act_apply(v, act);
+            for (int s = 0; s < MS; ++s)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { acc[s][j][0] = f2{0.f, 0.f}; acc[s][j][1] = f2{0.f, 0.f}; }
+        }
+        consume<WT, MS>(ring.r[SLOT], x, XB_LD, (ks * S::NQ + cc * 4) * WT::KV, acc);
+        if constexpr (cc == S::CPI - 1) {
+#pragma unroll
+            for (int s = 0; s < MS; ++s)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    part[(ks * MS + s) * S::N + n0 + j * S::G0] = (acc[s][j][0].x + acc[s][j][0].y) + (acc[s][j][1].x + acc[s][j][1].y);
+        }
     }
-    __syncthreads();
+    pin_acc<MS>(acc);
+    if constexpr (C < NC - BURST) {
+        refill<WT, CAQ, G, REL0, C>(ring, tid, rsrc, mo, nskip);
+        pin_acc<MS>(acc);
+    }
 }
-// N = 256 (KS = 2): the owner thread (sample ms = tid>>8, dim d = tid&255) picks up its own sum.
-template <int MS>
-__device__ __forceinline__ float owner256(int tid, const float* __restrict__ part) {
-    if (tid >= 256 * MS) return 0.f;
-    const int ms = tid >> 8, n = tid & 255;
-    return part[ms * 256 + n] + part[(MS + ms) * 256 + n];
+template <typename WT, bool CAQ, int MS, int G, int REL0, int NC, int BURST, int... Cs>
+__device__ __forceinline__ void gemv_chunks(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip,
+                                            const float* __restrict__ x, float* __restrict__ part, f2 (&acc)[MS][2][2],
+                                            std::integer_sequence<int, Cs...>) {
+    (gemv_chunk<WT, CAQ, MS, G, REL0, NC, BURST, Cs>(ring, tid, rsrc, mo, nskip, x, part, acc), ...);
+}
+
+// Streaming half of GEMV G: every wave consumes its chunks (ring slots were requested earlier), publishes the
+// partial sums (barrier A) and then requests the withheld chunks, which keeps the L1 fill path busy while the
+// epilogue wave(s) turn the partial sums into the next GEMV's input.  The caller runs the epilogue and then
+// barrier B.  On entry and exit DEN_R chunks are in flight ahead of the consumer.
+template <typename WT, bool CAQ, int MS, int G, bool LAST>
+__device__ __forceinline__ void gemv_stream(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip,
+                                            const float* __restrict__ x, float* __restrict__ part) {
+    typedef Prog<WT, CAQ> P;
+    constexpr int REL0 = (G == G_SKIP) ? -P::TS : P::start(P::pos(G));
+    constexpr int NC = GS<WT, G>::TOT + (LAST ? P::PAD : 0);
+    constexpr int BURST = NC < 2 ? NC : 2;
+    asm volatile("" : "+v"(tid));   // addresses are recomputed per GEMV, not kept live across the layer body
+    f2 acc[MS][2][2];
+#pragma unroll
+    for (int s = 0; s < MS; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc[s][j][0] = f2{0.f, 0.f}; acc[s][j][1] = f2{0.f, 0.f}; }
+    gemv_chunks<WT, CAQ, MS, G, REL0, NC, BURST>(ring, tid, rsrc, mo, nskip, x, part, acc, std::make_integer_sequence<int, NC>{});
+    __syncthreads();                                                  // barrier A: partial sums visible
+    refill<WT, CAQ, G, REL0, NC - BURST>(ring, tid, rsrc, mo, nskip);
+    if constexpr (BURST == 2) refill<WT, CAQ, G, REL0, NC - 1>(ring, tid, rsrc, mo, nskip);
+    pin_acc<MS>(acc);
 }
 
 // ------------------------------------------------------------------ wave-local vector algebra
-// Between two GEMVs every wave redundantly owns the WHOLE 256-vector, 4 consecutive dims per lane
-// (dims 4*lane .. 4*lane+3).  LayerNorm / softmax / dot products are then wave reductions (DPP
-// butterflies) instead of workgroup reductions, so the only workgroup barrier per GEMV is the one
-// that publishes the partial sums.
+// The epilogue wave of a sample owns the WHOLE 256-vector, 4 consecutive dims per lane (dims 4*lane ..
+// 4*lane+3), so LayerNorm / softmax / dot products are wave reductions (DPP butterflies).
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 f4_fma(float s, float4 a, float4 acc) {
@@ -243,17 +311,25 @@ __device__ __forceinline__ float4 f4_silu(float4 v) {
     return make_float4(act_apply(v.x, SEEME_ACT_SILU), act_apply(v.y, SEEME_ACT_SILU), act_apply(v.z, SEEME_ACT_SILU),
                        act_apply(v.w, SEEME_ACT_SILU));
 }
-// sum of the two k-slice partials of a 256-output GEMV for sample s, dims 4*lane..
-template <int MS>
+__device__ __forceinline__ float4 f4_adaln(float4 h, float4 scl, float4 shf) {
+    return make_float4(h.x * (1.f + scl.x) + shf.x, h.y * (1.f + scl.y) + shf.y, h.z * (1.f + scl.z) + shf.z, h.w * (1.f + scl.w) + shf.w);
+}
+// sum of the KS k-slice partials of an N-output GEMV for sample s, outputs off + 4*lane ..
+template <int MS, int KS, int N>
+__device__ __forceinline__ float4 part_sum(const float* __restrict__ part, int s, int off, int lane) {
+    float4 v = ld4(part + s * N + off + 4 * lane);
+#pragma unroll
+    for (int k2 = 1; k2 < KS; ++k2) v = f4_add(v, ld4(part + (k2 * MS + s) * N + off + 4 * lane));
+    return v;
+}
+template <typename WT, int MS>
 __device__ __forceinline__ float4 part256(const float* __restrict__ part, int s, int lane) {
-    return f4_add(ld4(part + s * 256 + 4 * lane), ld4(part + (MS + s) * 256 + 4 * lane));
+    return part_sum<MS, GS<WT, G_OUTP>::KS, 256>(part, s, 0, lane);
 }
 
 // ------------------------------------------------------------------ the persistent sampling kernel
-#define FF_SA 1024   // sa_block feed-forward, hard-coded in the reference (mdiff_transformer.py:279)
-#define FF_D 128     // ffn_dim (configs/modules/denoiser.yaml:5)
 #define VP_LAYER (256 + 768 + 256 * 3 + FF_SA + 256 * 9 + FF_D + 256 * 4)   // floats of vector params per layer
-#define XB_LD 1024   // row stride of the GEMV input buffers
+#define STG_TT 1536  // time-token K|V (512) + AdaLN rows (1024) of one layer
 
 struct DenKArgs {
     const void* wg; int wg_bytes; const float* vp;
@@ -262,75 +338,113 @@ struct DenKArgs {
     SeemeSampleArgs s;
 };
 
-template <typename WT, int MS>
+// Per-layer small operands (biases / LayerNorm params, the time token's K|V and AdaLN rows, the condition
+// tokens' K|V) travel global -> LDS by LDS-DMA (no registers), one layer AHEAD of their use, into the other
+// half of a double buffer: requested at the top of layer l for layer l+1, 1 KiB per wave-instruction spread
+// over the 8 waves.  vmcnt retires in issue order, so once a wave has consumed any weight chunk it requested
+// later, its copies have landed; the barriers of layer l then publish them.  (hipcc does not count the asm
+// DMA: its own vmcnt(N) waits only become slightly longer, never shorter.)
+template <int MS>
+__device__ __forceinline__ void stage_dma(int wave, int lane, float* __restrict__ stg, const float* __restrict__ vpg,
+                                          const DenLayerOff* __restrict__ L, const float* __restrict__ tt_row, int l,
+                                          const SeemeSampleArgs& A, int b, int N) {
+    const uint32_t base = lds_addr_of(stg);
+    const int total = 31 + 4 * MS * N;
+#pragma unroll 1
+    for (int c = wave; c < total; c += DEN_THREADS / 64) {
+        const float* src;
+        int dst, lanes = 64;
+        if (c < 25) {                       // VP_LAYER = 24.5 KiB of vector params
+            src = vpg + L->skip_b + c * 256; dst = c * 256; if (c == 24) lanes = (VP_LAYER - 24 * 256) / 4;
+        } else if (c < 27) {                // time token K|V of this layer's sa_block
+            src = tt_row + l * 512 + (c - 25) * 256; dst = VP_LAYER + (c - 25) * 256;
+        } else if (c < 31) {                // AdaLN scale|shift rows (ca, ffn)
+            src = tt_row + 2560 + l * 1024 + (c - 27) * 256; dst = VP_LAYER + 512 + (c - 27) * 256;
+        } else {                            // condition tokens: sa K|V (512) | ca key|value (512) per (sample, token)
+            const int j = c - 31, sn = j >> 2, q = j & 3;
+            const int s = sn / N, n = sn - s * N;
+            const int bc = (MS == 2 && s == 1) ? A.B + b : b;     // CFG: s 0 = uncond (first half), s 1 = cond
+            src = A.ctab + ((size_t)bc * N + n) * SEEME_CROW + (q < 2 ? l * 512 + q * 256 : 2560 + l * 512 + (q - 2) * 256);
+            dst = VP_LAYER + STG_TT + sn * 1024 + q * 256;
+        }
+        if (lane < lanes) lds_dma_1k(src + 4 * lane, base + (uint32_t)dst * 4u);
+    }
+}
+
+template <typename WT, int MS, bool CAQ>
 __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef Prog<WT, CAQ> P;
     // wave-uniform buffer descriptor of the packed weight image (raw buffer loads: VGPR offset + SGPR offset)
     const __amdgpu_buffer_rsrc_t wg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ka.wg), 0, ka.wg_bytes, 0x00020000);
     const float* __restrict__ vp = ka.vp;
     const DenLayout* __restrict__ lay = ka.lay;
     const SeemeSampleArgs& A = ka.s;
     const int tid0 = threadIdx.x;
-    const int b = blockIdx.x, N = A.N, NS = N + 2, H = ka.nhead;
+    const int b = blockIdx.x, N = A.N, H = ka.nhead;
     const int seg = 64 / H;                      // lanes per attention head
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int lane = tid0 & 63;
+#ifdef DEN_DBG_NOEPI   // timing probe: no epilogues (results are garbage)
+    const bool epi = false;
+#else
+    const bool epi = wave < MS;                  // wave s turns sample s's partial sums into the next input vector
+#endif
+    const int es = epi ? wave : 0;
+    const int stg_sz = VP_LAYER + STG_TT + MS * N * 1024;
 
-    float* VP = smem;                            // [VP_LAYER]      this layer's biases / LayerNorm params
-    float* TTS = VP + VP_LAYER;                  // [1536]          time-token K|V (512) + AdaLN rows (1024)
-    float* CTS = TTS + 1536;                     // [MS][4][1024]   condition K|V (sa 512 | ca 512) per token
-    float* XB = CTS + MS * 4 * 1024;             // [2][MS][XB_LD]  GEMV inputs, ping-pong
-    float* PART = XB + 2 * MS * XB_LD;           // [2][2*MS*768]   GEMV partial sums, ping-pong
-    const int PART_SZ = 2 * MS * 768;
-    int pp = 0;
-
-    typedef GemvShape<WT, 512, 256> G_SKIP;
-    typedef GemvShape<WT, 256, 768> G_INP;
-    typedef GemvShape<WT, 256, 256> G_SQ;
-    typedef GemvShape<WT, 256, FF_SA> G_L1;
-    typedef GemvShape<WT, FF_SA, 256> G_L2;
-    typedef GemvShape<WT, 256, FF_D> G_F1;
-    typedef GemvShape<WT, FF_D, 256> G_F2;
+    float* CONSTV = smem;                        // [768]            query_pos.pe[0], encoder.norm.{weight,bias}
+    float* STG = CONSTV + 768;                   // [2][stg_sz]      per-layer operands, double-buffered
+    float* XB = STG + 2 * stg_sz;                // [MS][XB_LD]      GEMV input
+    float* PART = XB + MS * XB_LD;               // [4*MS*768]       GEMV partial sums (k-slice major)
+    float* const xme = XB + es * XB_LD;
 
     const float sa_scale = 1.f / sqrtf((float)(256 / H));
-    float4 lat = ld4(A.latents + (size_t)b * 256 + 4 * (tid0 & 63));   // every wave holds the latent, 4 dims per lane
-    WBuf Abuf, Bbuf;                             // the two weight chunks in flight across GEMV boundaries
+    if (epi) __builtin_amdgcn_s_setprio(3);      // the chain of dependent epilogues is the critical path
+    float4 lat = ld4(A.latents + (size_t)b * 256 + 4 * lane);
+    float4 xr = lat, sk0 = lat, sk1 = lat;
+
+    // ---- prologue: constants, layer 0 operands, first input vector, first DEN_R chunks
+    int row = A.trow_per_sample ? A.trow[b] : A.trow[0];
     {
-        const NextPre p0 = G_INP::pre(tid0, lay->L[0].inp);
-        issue_n<G_INP::CH>(Abuf, wg, p0.voff, p0.soff, p0.stride);
-        issue_n<G_INP::CH>(Bbuf, wg, p0.voff, p0.soff + (unsigned)(G_INP::CH * p0.stride), p0.stride);
+        for (int i = tid0; i < 192; i += DEN_THREADS)
+            st4(CONSTV + 4 * i, i < 64 ? ld4(vp + lay->pe0 + 4 * i) : (i < 128 ? ld4(vp + lay->fnw + 4 * (i - 64)) : ld4(vp + lay->fnb + 4 * (i - 128))));
+        stage_dma<MS>(wave, lane, STG, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b, N);
+        wait_vmcnt0();
+        __syncthreads();
+        if (epi) { xr = f4_add(lat, ld4(CONSTV + 4 * lane)); sk0 = xr; sk1 = xr; st4(xme + 4 * lane, xr); }   // mld_denoiser.py:210
     }
+    Ring ring;
+    {
+        const MatOffs m0 = load_mat_offs<WT>(&lay->L[0], &lay->L[1], false);
+        issue_p0<WT, CAQ, 0>(ring, tid0, wg, m0); issue_p0<WT, CAQ, 1>(ring, tid0, wg, m0);
+        issue_p0<WT, CAQ, 2>(ring, tid0, wg, m0); issue_p0<WT, CAQ, 3>(ring, tid0, wg, m0);
+        static_assert(DEN_R == 4, "prologue issues four chunks");
+    }
+    __syncthreads();
+    int cur = 0;                                 // which half of STG holds the current layer
 
 #pragma unroll 1
     for (int step = 0; step < A.steps; ++step) {
-        const int row = A.trow_per_sample ? A.trow[b] : A.trow[step];
-        const float* __restrict__ tt = A.ttab + (size_t)row * SEEME_TROW;
-        float4 xr[MS], sk0[MS], sk1[MS];
-        {
-            const float4 pe = ld4(vp + lay->pe0 + 4 * (tid0 & 63));       // mld_denoiser.py:210
-#pragma unroll
-            for (int s = 0; s < MS; ++s) { xr[s] = f4_add(lat, pe); sk0[s] = xr[s]; sk1[s] = xr[s]; }
-        }
-
+        // table row of the NEXT step (the last layer stages layer 0 of the next step)
+        const int row_next = A.trow_per_sample ? row : A.trow[step + 1 < A.steps ? step + 1 : step];
 #pragma unroll 1
         for (int l = 0; l < SEEME_DEN_NL; ++l) {
             const DenLayerOff* __restrict__ L = &lay->L[l];
+            const int ln = (l + 1 < SEEME_DEN_NL) ? l + 1 : 0;
+            const DenLayerOff* __restrict__ Ln = &lay->L[ln];
+            const bool nskip = ln >= 3;
+            const MatOffs mo = load_mat_offs<WT>(L, Ln, nskip);
             // Launder the thread id once per layer: every address derived from it is then recomputed inside
-            // the layer body instead of being hoisted out of the loops (which costs >100 live VGPRs and spills).
+            // the layer body instead of being hoisted out of the loops.
             int tid = tid0;
             asm volatile("" : "+v"(tid));
-            const int lane = tid & 63;
-            // ---- stage this layer's small operands in LDS (one latency per layer instead of one per epilogue:
-            //      an ordinary load issued behind a weight chunk returns behind it)
-            __syncthreads();                                   // everyone is done with the previous layer's copies
-            for (int i = tid; i < VP_LAYER / 4; i += DEN_THREADS) st4(VP + 4 * i, ld4(vp + L->skip_b + 4 * i));
-            for (int i = tid; i < 1536 / 4; i += DEN_THREADS)
-                st4(TTS + 4 * i, i < 128 ? ld4(tt + l * 512 + 4 * i) : ld4(tt + 2560 + l * 1024 + 4 * (i - 128)));
-            for (int i = tid; i < MS * N * 256; i += DEN_THREADS) {     // float4 index over [MS][N][1024]
-                const int s = i / (N * 256), r = i - s * (N * 256), n = r >> 8, c = r & 255;
-                const int bc = (MS == 2 && s == 1) ? A.B + b : b;       // CFG: s 0 = uncond (first half), s 1 = cond
-                const float* src = A.ctab + ((size_t)bc * N + n) * SEEME_CROW + (c < 128 ? l * 512 + 4 * c : 2560 + l * 512 + 4 * (c - 128));
-                st4(CTS + (s * 4 + n) * 1024 + 4 * c, ld4(src));
-            }
-            __syncthreads();
+            const float* VP = STG + cur * stg_sz;            // this layer's biases / LayerNorm params
+            const float* TTS = VP + VP_LAYER;                // time-token K|V (512) + AdaLN rows (1024)
+            const float* CTS = TTS + STG_TT;                 // [MS][N][1024] condition K|V (sa 512 | ca 512)
+            const float* CT = CTS + es * N * 1024;
+            // request the next layer's operands (LDS-DMA into the other half of the double buffer)
+            stage_dma<MS>(wave, lane, STG + (cur ^ 1) * stg_sz, vp, Ln, A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW, ln, A, b, N);
             // offsets inside VP (relative to skip_b)
             const float* v_skip_b = VP;
             const float* v_in_b = VP + (L->in_b - L->skip_b);
@@ -346,106 +460,83 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             const float* v_fsnw = VP + (L->fsnw - L->skip_b), *v_fsnb = VP + (L->fsnb - L->skip_b);
             const float* v_fo_b = VP + (L->fo_b - L->skip_b);
 
-            // ---- skip connection: Linear(cat[x, xs.pop()])  (cross_attention.py:77-79)
+            // ---- skip connection: Linear(cat[x, xs.pop()])  (cross_attention.py:77-79); input staged by the
+            //      previous layer's last epilogue
             if (l >= 3) {
-                float* xb = XB + pp * MS * XB_LD;
-#pragma unroll
-                for (int s = 0; s < MS; ++s) {
-                    st4(xb + s * XB_LD + 4 * lane, xr[s]);
-                    st4(xb + s * XB_LD + 256 + 4 * lane, l == 3 ? sk1[s] : sk0[s]);
+                gemv_stream<WT, CAQ, MS, G_SKIP, false>(ring, tid, wg, mo, nskip, XB, PART);
+                if (epi) {
+                    xr = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_skip_b + 4 * lane));
+                    st4(xme + 4 * lane, xr);
                 }
-                gemv_run<WT, 512, 256, MS, G_INP::CH>(tid, wg, L->skip, xb, XB_LD, Abuf, Bbuf, G_INP::pre(tid, L->inp), PART + pp * PART_SZ);
-#pragma unroll
-                for (int s = 0; s < MS; ++s) xr[s] = f4_add(part256<MS>(PART + pp * PART_SZ, s, lane), ld4(v_skip_b + 4 * lane));
-                pp ^= 1;
+                __syncthreads();
             }
             // ---- sa_block: post-norm encoder layer over [x, xf.., emb]; only token 0 is kept
             //      (mdiff_transformer.py:292-297); K/V of xf and emb come from the tables.
-            {
-                float* xb = XB + pp * MS * XB_LD;
+            gemv_stream<WT, CAQ, MS, G_INP, false>(ring, tid, wg, mo, nskip, XB, PART);
+            if (epi) {
+                // in_proj output n in [0,768): q | k | v
+                constexpr int KSI = GS<WT, G_INP>::KS;
+                const float4 q = f4_add(part_sum<MS, KSI, 768>(PART, es, 0, lane), ld4(v_in_b + 4 * lane));
+                const float4 k0 = f4_add(part_sum<MS, KSI, 768>(PART, es, 256, lane), ld4(v_in_b + 256 + 4 * lane));
+                const float4 v0 = f4_add(part_sum<MS, KSI, 768>(PART, es, 512, lane), ld4(v_in_b + 512 + 4 * lane));
+                float sc[DEN_MAXTOK];
+                sc[0] = seg_reduce<false>(f4_dot(q, k0), seg) * sa_scale;
+                float mx = sc[0];
 #pragma unroll
-                for (int s = 0; s < MS; ++s) st4(xb + s * XB_LD + 4 * lane, xr[s]);
-                gemv_run<WT, 256, 768, MS, G_SQ::CH>(tid, wg, L->inp, xb, XB_LD, Abuf, Bbuf, G_SQ::pre(tid, L->outp), PART + pp * PART_SZ);
-                const float* P = PART + pp * PART_SZ;
-                pp ^= 1;
-                float* xn = XB + pp * MS * XB_LD;
+                for (int j = 0; j < DEN_MAXTOK - 2; ++j)
+                    if (j < N) { sc[1 + j] = seg_reduce<false>(f4_dot(q, ld4(CT + j * 1024 + 4 * lane)), seg) * sa_scale; mx = fmaxf(mx, sc[1 + j]); }
+                // the time token is the LAST of the sequence (mdiff_transformer.py:295)
+                const float st = seg_reduce<false>(f4_dot(q, ld4(TTS + 4 * lane)), seg) * sa_scale;
+                mx = fmaxf(mx, st);
+                float e0 = expf(sc[0] - mx), et = expf(st - mx), sum = e0 + et;
 #pragma unroll
-                for (int s = 0; s < MS; ++s) {
-                    // in_proj output n in [0,768): q | k | v, two k-slices
-                    const float4 q = f4_add(f4_add(ld4(P + s * 768 + 4 * lane), ld4(P + (MS + s) * 768 + 4 * lane)), ld4(v_in_b + 4 * lane));
-                    const float4 k0 = f4_add(f4_add(ld4(P + s * 768 + 256 + 4 * lane), ld4(P + (MS + s) * 768 + 256 + 4 * lane)), ld4(v_in_b + 256 + 4 * lane));
-                    const float4 v0 = f4_add(f4_add(ld4(P + s * 768 + 512 + 4 * lane), ld4(P + (MS + s) * 768 + 512 + 4 * lane)), ld4(v_in_b + 512 + 4 * lane));
-                    float sc[DEN_MAXTOK];
-                    sc[0] = seg_reduce<false>(f4_dot(q, k0), seg) * sa_scale;
-                    float mx = sc[0];
+                for (int j = 0; j < DEN_MAXTOK - 2; ++j) if (j < N) { sc[1 + j] = expf(sc[1 + j] - mx); sum += sc[1 + j]; }
+                const float inv = 1.f / sum;
+                float4 att = f4_scale(v0, e0 * inv);
 #pragma unroll
-                    for (int j = 0; j < DEN_MAXTOK - 2; ++j)
-                        if (j < N) { sc[1 + j] = seg_reduce<false>(f4_dot(q, ld4(CTS + (s * 4 + j) * 1024 + 4 * lane)), seg) * sa_scale; mx = fmaxf(mx, sc[1 + j]); }
-                    // the time token is the LAST of the sequence (mdiff_transformer.py:295)
-                    const float st = seg_reduce<false>(f4_dot(q, ld4(TTS + 4 * lane)), seg) * sa_scale;
-                    mx = fmaxf(mx, st);
-                    float e0 = expf(sc[0] - mx), et = expf(st - mx), sum = e0 + et;
-#pragma unroll
-                    for (int j = 0; j < DEN_MAXTOK - 2; ++j) if (j < N) { sc[1 + j] = expf(sc[1 + j] - mx); sum += sc[1 + j]; }
-                    const float inv = 1.f / sum;
-                    float4 att = f4_scale(v0, e0 * inv);
-#pragma unroll
-                    for (int j = 0; j < DEN_MAXTOK - 2; ++j)
-                        if (j < N) att = f4_fma(sc[1 + j] * inv, ld4(CTS + (s * 4 + j) * 1024 + 256 + 4 * lane), att);
-                    att = f4_fma(et * inv, ld4(TTS + 256 + 4 * lane), att);
-                    st4(xn + s * XB_LD + 4 * lane, att);
-                }
-                (void)NS;
+                for (int j = 0; j < DEN_MAXTOK - 2; ++j)
+                    if (j < N) att = f4_fma(sc[1 + j] * inv, ld4(CT + j * 1024 + 256 + 4 * lane), att);
+                att = f4_fma(et * inv, ld4(TTS + 256 + 4 * lane), att);
+                st4(xme + 4 * lane, att);
             }
-            {   // out_proj + residual + norm1
-                float* xb = XB + pp * MS * XB_LD;
-                gemv_run<WT, 256, 256, MS, G_L1::CH>(tid, wg, L->outp, xb, XB_LD, Abuf, Bbuf, G_L1::pre(tid, L->l1), PART + pp * PART_SZ);
-                const float* P = PART + pp * PART_SZ;
-                pp ^= 1;
-                float* xn = XB + pp * MS * XB_LD;
+            __syncthreads();
+            // ---- out_proj + residual + norm1
+            gemv_stream<WT, CAQ, MS, G_OUTP, false>(ring, tid, wg, mo, nskip, XB, PART);
+            if (epi) {
+                const float4 v = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_out_b + 4 * lane)));
+                xr = wave_ln(v, v_n1w, v_n1b, lane);
+                st4(xme + 4 * lane, xr);
+            }
+            __syncthreads();
+            // ---- linear1 + relu  (N = 1024, one k-slice)
+            gemv_stream<WT, CAQ, MS, G_L1, false>(ring, tid, wg, mo, nskip, XB, PART);
+            if (epi) {
 #pragma unroll
-                for (int s = 0; s < MS; ++s) {
-                    const float4 v = f4_add(xr[s], f4_add(part256<MS>(P, s, lane), ld4(v_out_b + 4 * lane)));
-                    xr[s] = wave_ln(v, v_n1w, v_n1b, lane);
-                    st4(xn + s * XB_LD + 4 * lane, xr[s]);
+                for (int j = 0; j < FF_SA / 256; ++j) {
+                    const float4 h = f4_add(part_sum<MS, GS<WT, G_L1>::KS, FF_SA>(PART, es, 256 * j, lane), ld4(v_l1b + 256 * j + 4 * lane));
+                    st4(xme + 256 * j + 4 * lane, make_float4(fmaxf(h.x, 0.f), fmaxf(h.y, 0.f), fmaxf(h.z, 0.f), fmaxf(h.w, 0.f)));
                 }
             }
-            {   // linear1 + relu  (N = 1024, one k-slice: outputs 4*lane + 256*j)
-                float* xb = XB + pp * MS * XB_LD;
-                gemv_run<WT, 256, FF_SA, MS, G_L2::CH>(tid, wg, L->l1, xb, XB_LD, Abuf, Bbuf, G_L2::pre(tid, L->l2), PART + pp * PART_SZ);
-                const float* P = PART + pp * PART_SZ;
-                pp ^= 1;
-                float* xn = XB + pp * MS * XB_LD;
-#pragma unroll
-                for (int s = 0; s < MS; ++s)
-#pragma unroll
-                    for (int j = 0; j < FF_SA / 256; ++j) {
-                        const float4 h = f4_add(ld4(P + s * FF_SA + 256 * j + 4 * lane), ld4(v_l1b + 256 * j + 4 * lane));
-                        st4(xn + s * XB_LD + 256 * j + 4 * lane, make_float4(fmaxf(h.x, 0.f), fmaxf(h.y, 0.f), fmaxf(h.z, 0.f), fmaxf(h.w, 0.f)));
-                    }
-            }
-            {   // linear2 + residual + norm2, then ca_block.norm -> query input
-                float* xb = XB + pp * MS * XB_LD;
-                gemv_run<WT, FF_SA, 256, MS, G_SQ::CH>(tid, wg, L->l2, xb, XB_LD, Abuf, Bbuf, G_SQ::pre(tid, L->caq), PART + pp * PART_SZ);
-                const float* P = PART + pp * PART_SZ;
-                pp ^= 1;
-                float* xn = XB + pp * MS * XB_LD;
-#pragma unroll
-                for (int s = 0; s < MS; ++s) {
-                    const float4 v = f4_add(xr[s], f4_add(part256<MS>(P, s, lane), ld4(v_l2b + 4 * lane)));
-                    xr[s] = wave_ln(v, v_n2w, v_n2b, lane);
-                    st4(xn + s * XB_LD + 4 * lane, wave_ln(xr[s], v_cnw, v_cnb, lane));
+            __syncthreads();
+            // ---- linear2 + residual + norm2, then ca_block (mdiff_transformer.py:219-239, 152-163)
+            gemv_stream<WT, CAQ, MS, G_L2, false>(ring, tid, wg, mo, nskip, XB, PART);
+            if (epi) {
+                const float4 v = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_l2b + 4 * lane)));
+                xr = wave_ln(v, v_n2w, v_n2b, lane);
+                if constexpr (CAQ) {
+                    st4(xme + 4 * lane, wave_ln(xr, v_cnw, v_cnb, lane));          // ca_block.norm -> query input
+                } else {
+                    // ONE condition token: the key softmax over tokens is exactly 1 and the query softmax sums to 1
+                    // per head, so q (k^T v) = v whatever the query is (:231-237) -- the query GEMV is skipped.
+                    const float4 hh = f4_adaln(wave_ln(ld4(CT + 768 + 4 * lane), v_csnw, v_csnb, lane), ld4(TTS + 512 + 4 * lane), ld4(TTS + 768 + 4 * lane));
+                    st4(xme + 4 * lane, f4_silu(hh));
                 }
             }
-            {   // ca_block: linear cross-attention + AdaLN (mdiff_transformer.py:219-239, 152-163)
-                float* xb = XB + pp * MS * XB_LD;
-                gemv_run<WT, 256, 256, MS, G_SQ::CH>(tid, wg, L->caq, xb, XB_LD, Abuf, Bbuf, G_SQ::pre(tid, L->cao), PART + pp * PART_SZ);
-                const float* P = PART + pp * PART_SZ;
-                pp ^= 1;
-                float* xn = XB + pp * MS * XB_LD;
-#pragma unroll
-                for (int s = 0; s < MS; ++s) {
-                    const float4 qv = f4_add(part256<MS>(P, s, lane), ld4(v_caq_b + 4 * lane));
+            __syncthreads();
+            if constexpr (CAQ) {
+                gemv_stream<WT, CAQ, MS, G_CAQ, false>(ring, tid, wg, mo, nskip, XB, PART);
+                if (epi) {
+                    const float4 qv = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_caq_b + 4 * lane));
                     const float mx = seg_reduce<true>(fmaxf(fmaxf(qv.x, qv.y), fmaxf(qv.z, qv.w)), seg);
                     const float4 e = make_float4(expf(qv.x - mx), expf(qv.y - mx), expf(qv.z - mx), expf(qv.w - mx));
                     const float inv = 1.f / seg_reduce<false>(e.x + e.y + e.z + e.w, seg);
@@ -456,7 +547,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
 #pragma unroll
                     for (int j = 0; j < DEN_MAXTOK - 2; ++j)
                         if (j < N) {
-                            kr[j] = ld4(CTS + (s * 4 + j) * 1024 + 512 + 4 * lane);
+                            kr[j] = ld4(CT + j * 1024 + 512 + 4 * lane);
                             kmx = make_float4(fmaxf(kmx.x, kr[j].x), fmaxf(kmx.y, kr[j].y), fmaxf(kmx.z, kr[j].z), fmaxf(kmx.w, kr[j].w));
                         }
                     float4 ks = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -472,118 +563,116 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                         if (j < N) {
                             const float4 kc = make_float4(kr[j].x / ks.x, kr[j].y / ks.y, kr[j].z / ks.z, kr[j].w / ks.w);
                             const float dot = seg_reduce<false>(f4_dot(qc, kc), seg);                      // q . k_n per head
-                            y = f4_fma(dot, ld4(CTS + (s * 4 + j) * 1024 + 768 + 4 * lane), y);            // (q k^T) v  (:236-237)
+                            y = f4_fma(dot, ld4(CT + j * 1024 + 768 + 4 * lane), y);                       // (q k^T) v  (:236-237)
                         }
-                    float4 hh = wave_ln(y, v_csnw, v_csnb, lane);
-                    const float4 scl = ld4(TTS + 512 + 4 * lane), shf = ld4(TTS + 768 + 4 * lane);
-                    hh = make_float4(hh.x * (1.f + scl.x) + shf.x, hh.y * (1.f + scl.y) + shf.y, hh.z * (1.f + scl.z) + shf.z, hh.w * (1.f + scl.w) + shf.w);
-                    st4(xn + s * XB_LD + 4 * lane, f4_silu(hh));
+                    const float4 hh = f4_adaln(wave_ln(y, v_csnw, v_csnb, lane), ld4(TTS + 512 + 4 * lane), ld4(TTS + 768 + 4 * lane));
+                    st4(xme + 4 * lane, f4_silu(hh));
                 }
+                __syncthreads();
             }
-            {   // proj_out.out_layers + residual
-                float* xb = XB + pp * MS * XB_LD;
-                gemv_run<WT, 256, 256, MS, G_F1::CH>(tid, wg, L->cao, xb, XB_LD, Abuf, Bbuf, G_F1::pre(tid, L->f1), PART + pp * PART_SZ);
-                const float* P = PART + pp * PART_SZ;
-                pp ^= 1;
-                float* xn = XB + pp * MS * XB_LD;
-#pragma unroll
-                for (int s = 0; s < MS; ++s) {
-                    xr[s] = f4_add(xr[s], f4_add(part256<MS>(P, s, lane), ld4(v_cao_b + 4 * lane)));
-                    st4(xn + s * XB_LD + 4 * lane, xr[s]);
+            // ---- proj_out.out_layers + residual
+            gemv_stream<WT, CAQ, MS, G_CAO, false>(ring, tid, wg, mo, nskip, XB, PART);
+            if (epi) {
+                xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_cao_b + 4 * lane)));
+                st4(xme + 4 * lane, xr);
+            }
+            __syncthreads();
+            // ---- ffn.linear1 + gelu  (N = 128, four k-slices: lanes 0..31 hold 4 outputs each)
+            gemv_stream<WT, CAQ, MS, G_F1, false>(ring, tid, wg, mo, nskip, XB, PART);
+            if (epi && lane < FF_D / 4) {
+                const float4 g = f4_add(part_sum<MS, GS<WT, G_F1>::KS, FF_D>(PART, es, 0, lane), ld4(v_f1b + 4 * lane));
+                st4(xme + 4 * lane, make_float4(act_apply(g.x, SEEME_ACT_GELU), act_apply(g.y, SEEME_ACT_GELU),
+                                                act_apply(g.z, SEEME_ACT_GELU), act_apply(g.w, SEEME_ACT_GELU)));
+            }
+            __syncthreads();
+            // ---- ffn.linear2 -> AdaLN
+            gemv_stream<WT, CAQ, MS, G_F2, false>(ring, tid, wg, mo, nskip, XB, PART);
+            if (epi) {
+                const float4 y2 = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_f2b + 4 * lane));
+                const float4 hh = f4_adaln(wave_ln(y2, v_fsnw, v_fsnb, lane), ld4(TTS + 1024 + 4 * lane), ld4(TTS + 1280 + 4 * lane));
+                st4(xme + 4 * lane, f4_silu(hh));
+            }
+            __syncthreads();
+            // ---- ffn.proj_out.out_layers + residual; its epilogue also prepares the input of the next layer
+            //      (or, after the last layer, runs the stack norm and the scheduler step)
+            gemv_stream<WT, CAQ, MS, G_FO, true>(ring, tid, wg, mo, nskip, XB, PART);
+            if (l + 1 < SEEME_DEN_NL) {
+                if (epi) {
+                    xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_fo_b + 4 * lane)));
+                    if (l == 0) sk0 = xr;
+                    if (l == 1) sk1 = xr;
+                    st4(xme + 4 * lane, xr);
+                    if (nskip) st4(xme + 256 + 4 * lane, ln == 3 ? sk1 : sk0);
                 }
-            }
-            {   // ffn.linear1 + gelu  (N = 128, four k-slices: lanes 0..31 hold 4 outputs each)
-                float* xb = XB + pp * MS * XB_LD;
-                gemv_run<WT, 256, FF_D, MS, G_F2::CH>(tid, wg, L->f1, xb, XB_LD, Abuf, Bbuf, G_F2::pre(tid, L->f2), PART + pp * PART_SZ);
-                const float* P = PART + pp * PART_SZ;
-                pp ^= 1;
-                float* xn = XB + pp * MS * XB_LD;
-                if (lane < FF_D / 4) {
-#pragma unroll
-                    for (int s = 0; s < MS; ++s) {
-                        float4 g = ld4(v_f1b + 4 * lane);
-#pragma unroll
-                        for (int k2 = 0; k2 < G_F1::KS; ++k2) g = f4_add(g, ld4(P + (k2 * MS + s) * FF_D + 4 * lane));
-                        st4(xn + s * XB_LD + 4 * lane, make_float4(act_apply(g.x, SEEME_ACT_GELU), act_apply(g.y, SEEME_ACT_GELU),
-                                                                   act_apply(g.z, SEEME_ACT_GELU), act_apply(g.w, SEEME_ACT_GELU)));
+                __syncthreads();
+            } else {
+                // ---- stack norm -> model output (cross_attention.py:82-83; mld_denoiser.py:222)
+                float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (epi) {
+                    xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_fo_b + 4 * lane)));
+                    e = wave_ln(xr, CONSTV + 256, CONSTV + 512, lane);
+                    if (MS == 2) st4(PART + es * 256 + 4 * lane, e);
+                }
+                if (MS == 2) {   // classifier-free guidance (mld.py:488-492), uncond (sample 0) first
+                    __syncthreads();
+                    if (epi) {
+                        const float4 eu = ld4(PART + 4 * lane), ec = ld4(PART + 256 + 4 * lane);
+                        const float g = A.guidance_scale;
+                        e = make_float4(eu.x + g * (ec.x - eu.x), eu.y + g * (ec.y - eu.y), eu.z + g * (ec.z - eu.z), eu.w + g * (ec.w - eu.w));
                     }
                 }
-            }
-            {   // ffn.linear2 -> AdaLN
-                float* xb = XB + pp * MS * XB_LD;
-                gemv_run<WT, FF_D, 256, MS, G_SQ::CH>(tid, wg, L->f2, xb, XB_LD, Abuf, Bbuf, G_SQ::pre(tid, L->fo), PART + pp * PART_SZ);
-                const float* P = PART + pp * PART_SZ;
-                pp ^= 1;
-                float* xn = XB + pp * MS * XB_LD;
+                if (A.sched == SEEME_SCHED_NONE) {   // steps == 1 by contract: the output is the model output
+                    lat = e;
+                } else if (epi) {
+                    // ---- scheduler.step (mld.py:495-497; scalars prepared by seeme_amd/schedulers.py)
+                    const float* __restrict__ c = A.coef + (size_t)step * 8;
+                    const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], clip = c[6], ptype = c[7];
+                    float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (A.noise != nullptr) nz = ld4(A.noise + ((size_t)step * A.B + b) * 256 + 4 * lane);
+                    const float xs[4] = {lat.x, lat.y, lat.z, lat.w}, es4[4] = {e.x, e.y, e.z, e.w}, ns[4] = {nz.x, nz.y, nz.z, nz.w};
+                    float o[4];
 #pragma unroll
-                for (int s = 0; s < MS; ++s) {
-                    const float4 y2 = f4_add(part256<MS>(P, s, lane), ld4(v_f2b + 4 * lane));
-                    float4 hh = wave_ln(y2, v_fsnw, v_fsnb, lane);
-                    const float4 scl = ld4(TTS + 1024 + 4 * lane), shf = ld4(TTS + 1280 + 4 * lane);
-                    hh = make_float4(hh.x * (1.f + scl.x) + shf.x, hh.y * (1.f + scl.y) + shf.y, hh.z * (1.f + scl.z) + shf.z, hh.w * (1.f + scl.w) + shf.w);
-                    st4(xn + s * XB_LD + 4 * lane, f4_silu(hh));
+                    for (int i = 0; i < 4; ++i) {
+                        float x0, ep;
+                        if (ptype == 0.f) { ep = es4[i]; x0 = (xs[i] - c1 * ep) / c0; }
+                        else              { x0 = es4[i]; ep = (xs[i] - c0 * x0) / c1; }
+                        if (clip != 0.f) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+                        o[i] = c2 * x0 + c3 * ep + c5 * xs[i] + c4 * ns[i];
+                    }
+                    lat = make_float4(o[0], o[1], o[2], o[3]);
+                    xr = f4_add(lat, ld4(CONSTV + 4 * lane));                        // next step: sample + query_pos
+                    sk0 = xr; sk1 = xr;
+                    st4(xme + 4 * lane, xr);
                 }
+                __syncthreads();
             }
-            {   // ffn.proj_out.out_layers + residual; the chunk requested now belongs to the next layer
-                //  (or to layer 0 of the next step)
-                float* xb = XB + pp * MS * XB_LD;
-                const int ln = (l + 1 < SEEME_DEN_NL) ? l + 1 : 0;
-                const NextPre nx = (ln >= 3) ? G_SKIP::pre(tid, lay->L[ln].skip) : G_INP::pre(tid, lay->L[ln].inp);
-                static_assert(G_SKIP::CH == G_INP::CH, "the two possible successors of the last GEMV of a layer must chunk alike");
-                gemv_run<WT, 256, 256, MS, G_INP::CH>(tid, wg, L->fo, xb, XB_LD, Abuf, Bbuf, nx, PART + pp * PART_SZ);
-                const float* P = PART + pp * PART_SZ;
-                pp ^= 1;
-#pragma unroll
-                for (int s = 0; s < MS; ++s) {
-                    xr[s] = f4_add(xr[s], f4_add(part256<MS>(P, s, lane), ld4(v_fo_b + 4 * lane)));
-                    if (l == 0) sk0[s] = xr[s];
-                    if (l == 1) sk1[s] = xr[s];
-                }
-            }
+            cur ^= 1;
         }
-        // ---- stack norm -> model output (cross_attention.py:82-83; mld_denoiser.py:222)
-        const int lane = tid0 & 63;
-        float4 e = wave_ln(xr[0], vp + lay->fnw, vp + lay->fnb, lane);
-        if (MS == 2) {   // classifier-free guidance (mld.py:488-492), uncond first
-            const float4 ec = wave_ln(xr[MS - 1], vp + lay->fnw, vp + lay->fnb, lane);
-            const float g = A.guidance_scale;
-            e = make_float4(e.x + g * (ec.x - e.x), e.y + g * (ec.y - e.y), e.z + g * (ec.z - e.z), e.w + g * (ec.w - e.w));
-        }
-        if (A.sched == SEEME_SCHED_NONE) { lat = e; break; }   // steps == 1 by contract: the output is the model output
-        // ---- scheduler.step (mld.py:495-497; scalars prepared by seeme_amd/schedulers.py)
-        {
-            const float* __restrict__ c = A.coef + (size_t)step * 8;
-            const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], clip = c[6], ptype = c[7];
-            float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (A.noise != nullptr) nz = ld4(A.noise + ((size_t)step * A.B + b) * 256 + 4 * lane);
-            const float xs[4] = {lat.x, lat.y, lat.z, lat.w}, es[4] = {e.x, e.y, e.z, e.w}, ns[4] = {nz.x, nz.y, nz.z, nz.w};
-            float o[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float x0, ep;
-                if (ptype == 0.f) { ep = es[i]; x0 = (xs[i] - c1 * ep) / c0; }
-                else              { x0 = es[i]; ep = (xs[i] - c0 * x0) / c1; }
-                if (clip != 0.f) x0 = fminf(fmaxf(x0, -1.f), 1.f);
-                o[i] = c2 * x0 + c3 * ep + c5 * xs[i] + c4 * ns[i];
-            }
-            lat = make_float4(o[0], o[1], o[2], o[3]);
-        }
+        row = row_next;
     }
     if (tid0 < 64) st4(A.out + (size_t)b * 256 + 4 * tid0, lat);
-    // the last requested chunk is never consumed: keep it from being optimised into a dangling load
-    asm volatile("" ::"v"(Abuf.r[0].x), "v"(Bbuf.r[0].x));
+    // the last requested chunks are never consumed: keep them from being optimised into dangling loads
+#pragma unroll
+    for (int s = 0; s < DEN_R; ++s) asm volatile("" ::"v"(ring.r[s][0].x));
 }
 
-static size_t den_lds_bytes(int MS) {
-    return (size_t)(VP_LAYER + 1536 + MS * 4 * 1024 + 2 * MS * XB_LD + 2 * (2 * MS * 768)) * sizeof(float);
+static size_t den_lds_bytes(int MS, int N) {
+    return (size_t)(768 + 2 * (VP_LAYER + STG_TT + MS * N * 1024) + MS * XB_LD + 4 * MS * 768) * sizeof(float);
 }
 
-template <typename WT, int MS>
+template <typename WT, int MS, bool CAQ>
 static int launch_den(const DenKArgs& ka, hipStream_t st) {
-    const size_t lds = den_lds_bytes(MS);
-    SEEME_HIP(hipFuncSetAttribute((const void*)k_den_sample<WT, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_den_sample<WT, MS>), dim3(ka.s.B), dim3(DEN_THREADS), lds, st, ka);
+    const size_t lds = den_lds_bytes(MS, ka.s.N);
+    if (lds > 160 * 1024) return seeme_fail("denoiser_sample: LDS budget exceeded");
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_den_sample<WT, MS, CAQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_den_sample<WT, MS, CAQ>), dim3(ka.s.B), dim3(DEN_THREADS), lds, st, ka);
     return seeme_check_launch("k_den_sample");
+}
+template <typename WT>
+static int launch_den_wt(const DenKArgs& ka, hipStream_t st) {
+    const bool caq = ka.s.N > 1;
+    if (ka.s.cfg) return caq ? launch_den<WT, 2, true>(ka, st) : launch_den<WT, 2, false>(ka, st);
+    return caq ? launch_den<WT, 1, true>(ka, st) : launch_den<WT, 1, false>(ka, st);
 }
 
 extern "C" int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeSampleArgs* a, void* stream) {
@@ -602,9 +691,9 @@ extern "C" int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeS
     }
     ka.nhead = w->nhead; ka.s = *a;
     hipStream_t st = (hipStream_t)stream;
-    if (w->wdtype == 0) return a->cfg ? launch_den<WF32, 2>(ka, st) : launch_den<WF32, 1>(ka, st);
-    if (w->wdtype == 1) return a->cfg ? launch_den<WBF16, 2>(ka, st) : launch_den<WBF16, 1>(ka, st);
-    if (w->wdtype == 2) return a->cfg ? launch_den<WF16, 2>(ka, st) : launch_den<WF16, 1>(ka, st);
+    if (w->wdtype == 0) return launch_den_wt<WF32>(ka, st);
+    if (w->wdtype == 1) return launch_den_wt<WBF16>(ka, st);
+    if (w->wdtype == 2) return launch_den_wt<WF16>(ka, st);
     return seeme_fail("denoiser_sample: wdtype must be 0 (fp32), 1 (bf16) or 2 (fp16)");
 }
 

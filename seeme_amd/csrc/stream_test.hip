@@ -128,3 +128,155 @@ extern "C" int seeme_debug_stream(const float* src, long bytes, int reps, int mo
     }
     return seeme_check_launch("k_stream");
 }
+
+#define PIN() do { asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+// mode 3: register ring of R chunks (8 x 16 B per lane each) -- the in-flight depth experiment behind the
+// sampling kernel's weight pipeline.  Consumes chunk t, re-fills its slot with chunk t + R; a workgroup
+// barrier + wave-local epilogue every `per_gemv` chunks (per_gemv % R == 0 or 0).
+template <int R>
+__global__ __launch_bounds__(512) void k_stream_rr(const float4* __restrict__ src, int bytes, long nchunks,
+                                                   int per_gemv, int epi_iters, float* __restrict__ out) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int CH = 8;
+    __shared__ float red[512];
+    const int tid = threadIdx.x;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(src), 0, bytes, 0x00020000);
+    const unsigned voff = (unsigned)tid * 16u;
+    const unsigned chunk_bytes = CH * 512 * 16;
+    const unsigned wrap = (unsigned)bytes / chunk_bytes * chunk_bytes;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    u32x4 ring[R][CH];
+    unsigned soff = 0;
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) ring[s][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + i * 8192u, 0);
+        soff += chunk_bytes; if (soff >= wrap) soff = 0;
+    }
+    int since = 0;
+#pragma unroll 1
+    for (long c = 0; c < nchunks; c += R) {
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                acc.x += __uint_as_float(ring[s][i].x); acc.y += __uint_as_float(ring[s][i].y);
+                acc.z += __uint_as_float(ring[s][i].z); acc.w += __uint_as_float(ring[s][i].w);
+            }
+            PIN();   // the re-fill reuses the registers just consumed
+#pragma unroll
+            for (int i = 0; i < CH; ++i) ring[s][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + i * 8192u, 0);
+            soff += chunk_bytes; if (soff >= wrap) soff = 0;
+            PIN();
+            if (per_gemv > 0 && ++since == per_gemv) {
+                since = 0;
+                red[tid] = acc.x;
+                __syncthreads();
+                float v = red[(tid + 64) & 511];
+                for (int e = 0; e < epi_iters; ++e) v = wave_sum(v) * 0.015625f + 1e-9f;
+                acc.w += v * 1e-30f;
+            }
+        }
+    }
+    out[(size_t)blockIdx.x * blockDim.x + tid] = (acc.x + acc.y) + (acc.z + acc.w);
+#pragma unroll
+    for (int s = 0; s < R; ++s) asm volatile("" ::"v"(ring[s][0].x));
+}
+
+extern "C" int seeme_debug_stream_rr(const float* src, long bytes, long nchunks, int ring, int per_gemv, int epi_iters,
+                                     int blocks, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (ring == 2) hipLaunchKernelGGL((k_stream_rr<2>), dim3(blocks), dim3(512), 0, st, (const float4*)src, (int)bytes, nchunks, per_gemv, epi_iters, out);
+    else if (ring == 3) hipLaunchKernelGGL((k_stream_rr<3>), dim3(blocks), dim3(512), 0, st, (const float4*)src, (int)bytes, nchunks, per_gemv, epi_iters, out);
+    else if (ring == 4) hipLaunchKernelGGL((k_stream_rr<4>), dim3(blocks), dim3(512), 0, st, (const float4*)src, (int)bytes, nchunks, per_gemv, epi_iters, out);
+    else if (ring == 6) hipLaunchKernelGGL((k_stream_rr<6>), dim3(blocks), dim3(512), 0, st, (const float4*)src, (int)bytes, nchunks, per_gemv, epi_iters, out);
+    else return seeme_fail("debug_stream_rr: ring must be 2, 3, 4 or 6");
+    return seeme_check_launch("k_stream_rr");
+}
+
+// mode 4: role-specialised variant of mode 3 (ring of 4).  Per "GEMV" of C chunks: every wave consumes C chunks,
+// re-filling only from the third consume on; barrier A; wave 0 runs the epilogue while waves 1..7 issue the two
+// withheld chunks (so the L1 fill path stays busy during the epilogue); barrier B; wave 0 issues its own two.
+template <int C, bool VOL>
+__global__ __launch_bounds__(512) void k_stream_spec(const float4* __restrict__ src, int bytes, long ngemv,
+                                                     int epi_iters, float* __restrict__ out) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int CH = 8, R = 4;
+    constexpr int AUX = VOL ? (int)0x80000000 : 0;
+    static_assert(C % R == 0 || C == 2, "slot phase must repeat per GEMV");
+    __shared__ float red[512];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(src), 0, bytes, 0x00020000);
+    const unsigned voff = (unsigned)tid * 16u;
+    const unsigned chunk_bytes = CH * 512 * 16;
+    const unsigned wrap = (unsigned)bytes / chunk_bytes * chunk_bytes;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    u32x4 ring[R][CH];
+    unsigned soff = 0;
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) ring[s][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + i * 8192u, AUX);
+        soff += chunk_bytes; if (soff >= wrap) soff = 0;
+    }
+    constexpr int UN = (C == 2) ? 2 : 1;   // GEMVs per loop trip so that slot indices are compile-time
+#pragma unroll 1
+    for (long g = 0; g < ngemv; g += UN) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            unsigned soff_b[2];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int s = (u * C + c) % R;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    acc.x += __uint_as_float(ring[s][i].x); acc.y += __uint_as_float(ring[s][i].y);
+                    acc.z += __uint_as_float(ring[s][i].z); acc.w += __uint_as_float(ring[s][i].w);
+                }
+                PIN();
+                if (c >= 2) {   // re-fill the slot consumed two chunks ago
+                    const int s2 = (u * C + c - 2) % R;
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) ring[s2][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + i * 8192u, AUX);
+                    soff += chunk_bytes; if (soff >= wrap) soff = 0;
+                }
+                PIN();
+            }
+            soff_b[0] = soff; soff += chunk_bytes; if (soff >= wrap) soff = 0;
+            soff_b[1] = soff; soff += chunk_bytes; if (soff >= wrap) soff = 0;
+            red[tid] = acc.x;
+            __syncthreads();                                         // barrier A: partial sums published
+            if (wave == 0) __builtin_amdgcn_s_setprio(3);           // the epilogue wave's requests go first
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int s2 = (u * C + C - 2 + b) % R;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) ring[s2][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff_b[b] + i * 8192u, AUX);
+            }
+            PIN();
+            if (wave == 0) {
+                float v = red[(tid + 64) & 511];
+                for (int e = 0; e < epi_iters; ++e) v = wave_sum(v) * 0.015625f + 1e-9f;
+                red[tid] = v;
+            }
+            __syncthreads();                                         // barrier B: next input vector published
+            acc.w += red[tid & 63] * 1e-30f;
+            PIN();
+        }
+    }
+    out[(size_t)blockIdx.x * blockDim.x + tid] = (acc.x + acc.y) + (acc.z + acc.w);
+#pragma unroll
+    for (int s = 0; s < R; ++s) asm volatile("" ::"v"(ring[s][0].x));
+}
+
+extern "C" int seeme_debug_stream_spec(const float* src, long bytes, long ngemv, int c, int vol, int epi_iters,
+                                       int blocks, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+#define SPEC_LAUNCH(CC, VV) hipLaunchKernelGGL((k_stream_spec<CC, VV>), dim3(blocks), dim3(512), 0, st, (const float4*)src, (int)bytes, ngemv, epi_iters, out)
+    if (c == 2 && vol) SPEC_LAUNCH(2, true); else if (c == 2) SPEC_LAUNCH(2, false);
+    else if (c == 4 && vol) SPEC_LAUNCH(4, true); else if (c == 4) SPEC_LAUNCH(4, false);
+    else if (c == 8 && vol) SPEC_LAUNCH(8, true); else if (c == 8) SPEC_LAUNCH(8, false);
+    else return seeme_fail("debug_stream_spec: c must be 2, 4 or 8");
+#undef SPEC_LAUNCH
+    return seeme_check_launch("k_stream_spec");
+}
