@@ -24,12 +24,20 @@
 #define DEN_CH 8       // 16-B vectors per lane per chunk (ring = 4 x 8 x 4 = 128 VGPRs)
 
 // ------------------------------------------------------------------ weight element types
-struct WF32 { typedef float T; static constexpr int KV = 4; static constexpr bool HALF = false; };      // 16-B vector = 4 weights
-struct WBF16 { typedef uint16_t T; static constexpr int KV = 8; static constexpr bool HALF = false; };  // 16-B vector = 8 bf16 weights
-struct WF16 { typedef uint16_t T; static constexpr int KV = 8; static constexpr bool HALF = true; };    // 16-B vector = 8 fp16 weights
+// fp32 weights run on the vector ALU (exact fp32 products).  16-bit weights run on the matrix cores: the
+// weight vector a lane streams IS its MFMA operand (16 outputs x 32 k per wave-load), and the fp32 input
+// vector enters as PARTS 16-bit rows (hi + lo [+ mid]) whose products are re-added in fp32, so the input is
+// not rounded to 16 bits -- only the weights are.
+struct WF32 { typedef float T; static constexpr int KV = 4; static constexpr bool HALF = false, MFMA = false; static constexpr int PARTS = 1; };
+struct WBF16 { typedef uint16_t T; static constexpr int KV = 8; static constexpr bool HALF = false, MFMA = true; static constexpr int PARTS = 3; };
+struct WF16 { typedef uint16_t T; static constexpr int KV = 8; static constexpr bool HALF = true, MFMA = true; static constexpr int PARTS = 2; };
+#define DEN_F16_LO_SCALE 2048.f   // fp16 input split: lo = (x - hi) * 2^11 stays in the normal range
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct Ring { u32x4 r[DEN_R][DEN_CH]; };
 
@@ -58,6 +66,10 @@ struct GS {
     static constexpr int CPI = NQ / 4;                                              // chunks per item
     static constexpr int TOT = IT * CPI;                                            // chunks per thread
     static_assert(G0 * KS == DEN_THREADS * IT && NQ * KS * WT::KV == K && NQ % 4 == 0 && TOT >= 1, "unsupported GEMV shape");
+    // matrix-core mapping (16-bit weights): wave w owns the TW output tiles (16 outputs each) w*TW .. w*TW+TW-1
+    // for ALL k; its stream is k-block major: wave-load i = (k-block i / TW, tile i % TW), 1 KiB each
+    static constexpr int TW = N / 16 / (DEN_THREADS / 64), KB = K / 32;
+    static_assert(!WT::MFMA || (TW * 16 * (DEN_THREADS / 64) == N && KB * 32 == K && TW * KB == TOT * DEN_CH), "unsupported MFMA GEMV shape");
     __device__ static __forceinline__ void item(int tid, int it, int& ks, int& n0) {
         const int idx = tid + it * DEN_THREADS;
         ks = idx / G0; n0 = idx - ks * G0;
@@ -101,6 +113,13 @@ __device__ __forceinline__ void issue_mat(u32x4 (&slot)[DEN_CH], int tid, __amdg
     return;
 #endif
     typedef GS<WT, G> S;
+    if constexpr (WT::MFMA) {
+        const unsigned voff = (unsigned)(tid >> 6) * (unsigned)(S::TW * S::KB * 1024) + (unsigned)(tid & 63) * 16u;
+        const unsigned soff = mat_bytes + (unsigned)(C * DEN_CH) * 1024u;
+#pragma unroll
+        for (int i = 0; i < DEN_CH; ++i) slot[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + (unsigned)(i * 1024), 0);
+        return;
+    }
     constexpr int it = C / S::CPI, cc = C % S::CPI;
     int ks, n0;
     S::item(tid, it, ks, n0);
@@ -192,16 +211,44 @@ __device__ __forceinline__ void consume(const u32x4 (&b)[DEN_CH], const float* _
     }
 }
 
-// Pin the program order: the accumulators pass through a side-effecting asm with a memory clobber, so the
-// arithmetic that read a ring slot stays above and the loads that re-fill the slot stay below it (otherwise
-// the instruction selector hoists the re-fill into fresh registers and the ring silently doubles).
-template <int MS>
-__device__ __forceinline__ void pin_acc(f2 (&acc)[MS][2][2]) {
+// Where a GEMV reads its input: fp32 path = the fp32 vector(s) in LDS (broadcast reads); matrix-core path = this
+// lane's row of the 16-bit input fragments, [k-block][k-group 4][row 4*MS][8 halves], rows 4s+p = part p of
+// sample s (lanes whose row is unused point at 16 zero bytes, stride 0).
+struct XIn { const float* xf; const char* frag; int fstride; };
+
+// Accumulators of one GEMV.  fp32 path: [sample][output half][2] packed pairs.  Matrix-core path: one 16x16
+// tile per owned output tile; lanes 16s .. 16s+15 end up with the PARTS partial products of sample s for the
+// tile's 16 outputs in elements 0 .. PARTS-1.
+template <typename WT, int MS, int G>
+struct Acc {
+    f2 v[WT::MFMA ? 1 : MS][2][2];
+    f32x4 m[WT::MFMA ? GS<WT, G>::TW : 1];
+    __device__ __forceinline__ void zero() {
+        if constexpr (WT::MFMA) {
 #pragma unroll
-    for (int s = 0; s < MS; ++s)
-        asm volatile("" : "+v"(acc[s][0][0]), "+v"(acc[s][0][1]), "+v"(acc[s][1][0]), "+v"(acc[s][1][1]) :: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
+            for (int t = 0; t < GS<WT, G>::TW; ++t) m[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int s = 0; s < MS; ++s)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { v[s][j][0] = f2{0.f, 0.f}; v[s][j][1] = f2{0.f, 0.f}; }
+        }
+    }
+    // Pin the program order: the accumulators pass through a side-effecting asm with a memory clobber, so the
+    // arithmetic that read a ring slot stays above and the loads that re-fill the slot stay below it (otherwise
+    // the instruction selector hoists the re-fill into fresh registers and the ring silently doubles).
+    __device__ __forceinline__ void pin() {
+        if constexpr (WT::MFMA) {
+#pragma unroll
+            for (int t = 0; t < GS<WT, G>::TW; ++t) asm volatile("" : "+v"(m[t]) :: "memory");
+        } else {
+#pragma unroll
+            for (int s = 0; s < MS; ++s)
+                asm volatile("" : "+v"(v[s][0][0]), "+v"(v[s][0][1]), "+v"(v[s][1][0]), "+v"(v[s][1][1]) :: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
 
 // One chunk step of a GEMV of the layer program.  REL0 = index of the GEMV's first chunk relative to the
 // layer's P0 (negative for the skip linear), C = local chunk, NC = chunks incl. padding.  Consuming chunk t
@@ -215,37 +262,60 @@ __device__ __forceinline__ void refill(Ring& ring, int tid, __amdgpu_buffer_rsrc
 }
 template <typename WT, bool CAQ, int MS, int G, int REL0, int NC, int BURST, int C>
 __device__ __forceinline__ void gemv_chunk(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip,
-                                           const float* __restrict__ x, float* __restrict__ part, f2 (&acc)[MS][2][2]) {
+                                           const XIn& x, float* __restrict__ part, Acc<WT, MS, G>& acc) {
     typedef GS<WT, G> S;
     constexpr int SLOT = ((REL0 + C) % DEN_R + DEN_R) % DEN_R;
-    if constexpr (C < S::TOT) {
+    if constexpr (C < S::TOT && WT::MFMA) {
+        // 8 wave-loads = 8 (k-block, tile) operands; the input fragment changes once per k-block
+        uint4 a4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int j = 0; j < DEN_CH; ++j) {
+            constexpr int dummy = 0; (void)dummy;
+            const int i = C * DEN_CH + j, kb = i / S::TW, t = i % S::TW;
+            if (j == 0 || t == 0) a4 = *reinterpret_cast<const uint4*>(x.frag + kb * x.fstride);
+#ifndef DEN_DBG_NOFMA
+            if constexpr (WT::HALF) acc.m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a4), __builtin_bit_cast(h16x8, ring.r[SLOT][j]), acc.m[t], 0, 0, 0);
+            else acc.m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a4), __builtin_bit_cast(bf16x8, ring.r[SLOT][j]), acc.m[t], 0, 0, 0);
+#else
+            acc.m[t].x += __uint_as_float(ring.r[SLOT][j].x ^ ring.r[SLOT][j].y ^ ring.r[SLOT][j].z ^ ring.r[SLOT][j].w ^ a4.x);
+#endif
+        }
+        if constexpr (C == S::TOT - 1) {
+            // lanes 16s .. 16s+15: outputs (wave*TW + t)*16 + lane%16 of sample s = sum of the input parts
+            const int lane = tid & 63, sl = lane >> 4;
+            if (sl < MS) {
+#pragma unroll
+                for (int t = 0; t < S::TW; ++t) {
+                    float val;
+                    if constexpr (WT::HALF) val = fmaf(acc.m[t].y, 1.f / DEN_F16_LO_SCALE, acc.m[t].x);
+                    else val = acc.m[t].x + (acc.m[t].y + acc.m[t].z);
+                    part[sl * S::N + ((tid >> 6) * S::TW + t) * 16 + (lane & 15)] = val;
+                }
+            }
+        }
+    } else if constexpr (C < S::TOT) {
         constexpr int it = C / S::CPI, cc = C % S::CPI;
         int ks, n0;
         S::item(tid, it, ks, n0);
-        if constexpr (cc == 0) {
-#pragma unroll
-            for (int s = 0; s < MS; ++s)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { acc[s][j][0] = f2{0.f, 0.f}; acc[s][j][1] = f2{0.f, 0.f}; }
-        }
-        consume<WT, MS>(ring.r[SLOT], x, XB_LD, (ks * S::NQ + cc * 4) * WT::KV, acc);
+        if constexpr (cc == 0) acc.zero();
+        consume<WT, MS>(ring.r[SLOT], x.xf, XB_LD, (ks * S::NQ + cc * 4) * WT::KV, acc.v);
         if constexpr (cc == S::CPI - 1) {
 #pragma unroll
             for (int s = 0; s < MS; ++s)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    part[(ks * MS + s) * S::N + n0 + j * S::G0] = (acc[s][j][0].x + acc[s][j][0].y) + (acc[s][j][1].x + acc[s][j][1].y);
+                    part[(ks * MS + s) * S::N + n0 + j * S::G0] = (acc.v[s][j][0].x + acc.v[s][j][0].y) + (acc.v[s][j][1].x + acc.v[s][j][1].y);
         }
     }
-    pin_acc<MS>(acc);
+    acc.pin();
     if constexpr (C < NC - BURST) {
         refill<WT, CAQ, G, REL0, C>(ring, tid, rsrc, mo, nskip);
-        pin_acc<MS>(acc);
+        acc.pin();
     }
 }
 template <typename WT, bool CAQ, int MS, int G, int REL0, int NC, int BURST, int... Cs>
 __device__ __forceinline__ void gemv_chunks(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip,
-                                            const float* __restrict__ x, float* __restrict__ part, f2 (&acc)[MS][2][2],
+                                            const XIn& x, float* __restrict__ part, Acc<WT, MS, G>& acc,
                                             std::integer_sequence<int, Cs...>) {
     (gemv_chunk<WT, CAQ, MS, G, REL0, NC, BURST, Cs>(ring, tid, rsrc, mo, nskip, x, part, acc), ...);
 }
@@ -256,22 +326,19 @@ __device__ __forceinline__ void gemv_chunks(Ring& ring, int tid, __amdgpu_buffer
 // barrier B.  On entry and exit DEN_R chunks are in flight ahead of the consumer.
 template <typename WT, bool CAQ, int MS, int G, bool LAST>
 __device__ __forceinline__ void gemv_stream(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip,
-                                            const float* __restrict__ x, float* __restrict__ part) {
+                                            const XIn& x, float* __restrict__ part) {
     typedef Prog<WT, CAQ> P;
     constexpr int REL0 = (G == G_SKIP) ? -P::TS : P::start(P::pos(G));
     constexpr int NC = GS<WT, G>::TOT + (LAST ? P::PAD : 0);
     constexpr int BURST = NC < 2 ? NC : 2;
     asm volatile("" : "+v"(tid));   // addresses are recomputed per GEMV, not kept live across the layer body
-    f2 acc[MS][2][2];
-#pragma unroll
-    for (int s = 0; s < MS; ++s)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { acc[s][j][0] = f2{0.f, 0.f}; acc[s][j][1] = f2{0.f, 0.f}; }
+    Acc<WT, MS, G> acc;
+    acc.zero();
     gemv_chunks<WT, CAQ, MS, G, REL0, NC, BURST>(ring, tid, rsrc, mo, nskip, x, part, acc, std::make_integer_sequence<int, NC>{});
     __syncthreads();                                                  // barrier A: partial sums visible
     refill<WT, CAQ, G, REL0, NC - BURST>(ring, tid, rsrc, mo, nskip);
     if constexpr (BURST == 2) refill<WT, CAQ, G, REL0, NC - 1>(ring, tid, rsrc, mo, nskip);
-    pin_acc<MS>(acc);
+    acc.pin();
 }
 
 // ------------------------------------------------------------------ wave-local vector algebra
@@ -322,14 +389,48 @@ __device__ __forceinline__ float4 part_sum(const float* __restrict__ part, int s
     for (int k2 = 1; k2 < KS; ++k2) v = f4_add(v, ld4(part + (k2 * MS + s) * N + off + 4 * lane));
     return v;
 }
+// outputs off + 4*lane .. of GEMV G for sample s (matrix-core path: no k-slices, [sample][N])
+template <typename WT, int MS, int G>
+__device__ __forceinline__ float4 gemv_out(const float* __restrict__ part, int s, int off, int lane) {
+    if constexpr (WT::MFMA) return ld4(part + s * GS<WT, G>::N + off + 4 * lane);
+    else return part_sum<MS, GS<WT, G>::KS, GS<WT, G>::N>(part, s, off, lane);
+}
 template <typename WT, int MS>
-__device__ __forceinline__ float4 part256(const float* __restrict__ part, int s, int lane) {
-    return part_sum<MS, GS<WT, G_OUTP>::KS, 256>(part, s, 0, lane);
+__device__ __forceinline__ float4 part256(const float* __restrict__ part, int s, int lane) { return gemv_out<WT, MS, G_OUTP>(part, s, 0, lane); }
+
+// The epilogue wave of sample s publishes input values k0 + 4*lane .. k0 + 4*lane + 3 of the next GEMV.
+template <typename WT, int MS>
+__device__ __forceinline__ void put_x(float* __restrict__ xb, int s, int k0, int lane, float4 v) {
+    if constexpr (!WT::MFMA) {
+        st4(xb + s * XB_LD + k0 + 4 * lane, v);
+    } else {
+        const int k = k0 + 4 * lane;
+        char* dst = reinterpret_cast<char*>(xb) + ((((k >> 5) * 4 + ((k >> 3) & 3)) * (4 * MS) + 4 * s) * 16) + (k & 7) * 2;
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+        if constexpr (WT::HALF) {
+            const h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            const h4 lo = {(_Float16)((v.x - (float)hi.x) * DEN_F16_LO_SCALE), (_Float16)((v.y - (float)hi.y) * DEN_F16_LO_SCALE),
+                           (_Float16)((v.z - (float)hi.z) * DEN_F16_LO_SCALE), (_Float16)((v.w - (float)hi.w) * DEN_F16_LO_SCALE)};
+            *reinterpret_cast<h4*>(dst) = hi;
+            *reinterpret_cast<h4*>(dst + 16) = lo;
+        } else {
+            const b4 hi = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+            const float4 r1 = make_float4(v.x - (float)hi.x, v.y - (float)hi.y, v.z - (float)hi.z, v.w - (float)hi.w);
+            const b4 mid = {(__bf16)r1.x, (__bf16)r1.y, (__bf16)r1.z, (__bf16)r1.w};
+            const b4 lo = {(__bf16)(r1.x - (float)mid.x), (__bf16)(r1.y - (float)mid.y), (__bf16)(r1.z - (float)mid.z), (__bf16)(r1.w - (float)mid.w)};
+            *reinterpret_cast<b4*>(dst) = hi;
+            *reinterpret_cast<b4*>(dst + 16) = mid;
+            *reinterpret_cast<b4*>(dst + 32) = lo;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ the persistent sampling kernel
 #define VP_LAYER (256 + 768 + 256 * 3 + FF_SA + 256 * 9 + FF_D + 256 * 4)   // floats of vector params per layer
 #define STG_TT 1536  // time-token K|V (512) + AdaLN rows (1024) of one layer
+// floats of the GEMV input buffer: fp32 vectors, or the 16-bit fragments (8 KiB per sample) + one zero vector
+#define XB_FLOATS(mfma, MS) ((mfma) ? (MS) * 2048 + 4 : (MS) * XB_LD)
 
 struct DenKArgs {
     const void* wg; int wg_bytes; const float* vp;
@@ -395,9 +496,17 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
 
     float* CONSTV = smem;                        // [768]            query_pos.pe[0], encoder.norm.{weight,bias}
     float* STG = CONSTV + 768;                   // [2][stg_sz]      per-layer operands, double-buffered
-    float* XB = STG + 2 * stg_sz;                // [MS][XB_LD]      GEMV input
-    float* PART = XB + MS * XB_LD;               // [4*MS*768]       GEMV partial sums (k-slice major)
-    float* const xme = XB + es * XB_LD;
+    float* XB = STG + 2 * stg_sz;                // fp32 path: [MS][XB_LD] GEMV input; matrix-core path: 16-bit input
+                                                 // fragments [32 k-blocks][4][4*MS rows][8] + 16 zero bytes
+    float* PART = XB + XB_FLOATS(WT::MFMA, MS);  // fp32 path: [4*MS*768] partial sums (k-slice major); matrix-core: [MS][1024]
+    XIn xin;
+    xin.xf = XB;
+    {
+        const int row = lane & 15, kg = lane >> 4;
+        const bool used = WT::MFMA && (row >> 2) < MS && (row & 3) < WT::PARTS;
+        xin.frag = reinterpret_cast<const char*>(XB) + (used ? (kg * 4 * MS + row) * 16 : MS * 8192);
+        xin.fstride = used ? 4 * 4 * MS * 16 : 0;
+    }
 
     const float sa_scale = 1.f / sqrtf((float)(256 / H));
     if (epi) __builtin_amdgcn_s_setprio(3);      // the chain of dependent epilogues is the critical path
@@ -410,9 +519,10 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
         for (int i = tid0; i < 192; i += DEN_THREADS)
             st4(CONSTV + 4 * i, i < 64 ? ld4(vp + lay->pe0 + 4 * i) : (i < 128 ? ld4(vp + lay->fnw + 4 * (i - 64)) : ld4(vp + lay->fnb + 4 * (i - 128))));
         stage_dma<MS>(wave, lane, STG, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b, N);
+        if (WT::MFMA) for (int i = tid0; i < XB_FLOATS(true, MS) / 4; i += DEN_THREADS) st4(XB + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
         wait_vmcnt0();
         __syncthreads();
-        if (epi) { xr = f4_add(lat, ld4(CONSTV + 4 * lane)); sk0 = xr; sk1 = xr; st4(xme + 4 * lane, xr); }   // mld_denoiser.py:210
+        if (epi) { xr = f4_add(lat, ld4(CONSTV + 4 * lane)); sk0 = xr; sk1 = xr; put_x<WT, MS>(XB, es, 0, lane, xr); }   // mld_denoiser.py:210
     }
     Ring ring;
     {
@@ -463,22 +573,21 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             // ---- skip connection: Linear(cat[x, xs.pop()])  (cross_attention.py:77-79); input staged by the
             //      previous layer's last epilogue
             if (l >= 3) {
-                gemv_stream<WT, CAQ, MS, G_SKIP, false>(ring, tid, wg, mo, nskip, XB, PART);
+                gemv_stream<WT, CAQ, MS, G_SKIP, false>(ring, tid, wg, mo, nskip, xin, PART);
                 if (epi) {
                     xr = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_skip_b + 4 * lane));
-                    st4(xme + 4 * lane, xr);
+                    put_x<WT, MS>(XB, es, 0, lane, xr);
                 }
                 __syncthreads();
             }
             // ---- sa_block: post-norm encoder layer over [x, xf.., emb]; only token 0 is kept
             //      (mdiff_transformer.py:292-297); K/V of xf and emb come from the tables.
-            gemv_stream<WT, CAQ, MS, G_INP, false>(ring, tid, wg, mo, nskip, XB, PART);
+            gemv_stream<WT, CAQ, MS, G_INP, false>(ring, tid, wg, mo, nskip, xin, PART);
             if (epi) {
                 // in_proj output n in [0,768): q | k | v
-                constexpr int KSI = GS<WT, G_INP>::KS;
-                const float4 q = f4_add(part_sum<MS, KSI, 768>(PART, es, 0, lane), ld4(v_in_b + 4 * lane));
-                const float4 k0 = f4_add(part_sum<MS, KSI, 768>(PART, es, 256, lane), ld4(v_in_b + 256 + 4 * lane));
-                const float4 v0 = f4_add(part_sum<MS, KSI, 768>(PART, es, 512, lane), ld4(v_in_b + 512 + 4 * lane));
+                const float4 q = f4_add(gemv_out<WT, MS, G_INP>(PART, es, 0, lane), ld4(v_in_b + 4 * lane));
+                const float4 k0 = f4_add(gemv_out<WT, MS, G_INP>(PART, es, 256, lane), ld4(v_in_b + 256 + 4 * lane));
+                const float4 v0 = f4_add(gemv_out<WT, MS, G_INP>(PART, es, 512, lane), ld4(v_in_b + 512 + 4 * lane));
                 float sc[DEN_MAXTOK];
                 sc[0] = seg_reduce<false>(f4_dot(q, k0), seg) * sa_scale;
                 float mx = sc[0];
@@ -497,44 +606,44 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                 for (int j = 0; j < DEN_MAXTOK - 2; ++j)
                     if (j < N) att = f4_fma(sc[1 + j] * inv, ld4(CT + j * 1024 + 256 + 4 * lane), att);
                 att = f4_fma(et * inv, ld4(TTS + 256 + 4 * lane), att);
-                st4(xme + 4 * lane, att);
+                put_x<WT, MS>(XB, es, 0, lane, att);
             }
             __syncthreads();
             // ---- out_proj + residual + norm1
-            gemv_stream<WT, CAQ, MS, G_OUTP, false>(ring, tid, wg, mo, nskip, XB, PART);
+            gemv_stream<WT, CAQ, MS, G_OUTP, false>(ring, tid, wg, mo, nskip, xin, PART);
             if (epi) {
                 const float4 v = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_out_b + 4 * lane)));
                 xr = wave_ln(v, v_n1w, v_n1b, lane);
-                st4(xme + 4 * lane, xr);
+                put_x<WT, MS>(XB, es, 0, lane, xr);
             }
             __syncthreads();
             // ---- linear1 + relu  (N = 1024, one k-slice)
-            gemv_stream<WT, CAQ, MS, G_L1, false>(ring, tid, wg, mo, nskip, XB, PART);
+            gemv_stream<WT, CAQ, MS, G_L1, false>(ring, tid, wg, mo, nskip, xin, PART);
             if (epi) {
 #pragma unroll
                 for (int j = 0; j < FF_SA / 256; ++j) {
-                    const float4 h = f4_add(part_sum<MS, GS<WT, G_L1>::KS, FF_SA>(PART, es, 256 * j, lane), ld4(v_l1b + 256 * j + 4 * lane));
-                    st4(xme + 256 * j + 4 * lane, make_float4(fmaxf(h.x, 0.f), fmaxf(h.y, 0.f), fmaxf(h.z, 0.f), fmaxf(h.w, 0.f)));
+                    const float4 h = f4_add(gemv_out<WT, MS, G_L1>(PART, es, 256 * j, lane), ld4(v_l1b + 256 * j + 4 * lane));
+                    put_x<WT, MS>(XB, es, 256 * j, lane, make_float4(fmaxf(h.x, 0.f), fmaxf(h.y, 0.f), fmaxf(h.z, 0.f), fmaxf(h.w, 0.f)));
                 }
             }
             __syncthreads();
             // ---- linear2 + residual + norm2, then ca_block (mdiff_transformer.py:219-239, 152-163)
-            gemv_stream<WT, CAQ, MS, G_L2, false>(ring, tid, wg, mo, nskip, XB, PART);
+            gemv_stream<WT, CAQ, MS, G_L2, false>(ring, tid, wg, mo, nskip, xin, PART);
             if (epi) {
                 const float4 v = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_l2b + 4 * lane)));
                 xr = wave_ln(v, v_n2w, v_n2b, lane);
                 if constexpr (CAQ) {
-                    st4(xme + 4 * lane, wave_ln(xr, v_cnw, v_cnb, lane));          // ca_block.norm -> query input
+                    put_x<WT, MS>(XB, es, 0, lane, wave_ln(xr, v_cnw, v_cnb, lane));          // ca_block.norm -> query input
                 } else {
                     // ONE condition token: the key softmax over tokens is exactly 1 and the query softmax sums to 1
                     // per head, so q (k^T v) = v whatever the query is (:231-237) -- the query GEMV is skipped.
                     const float4 hh = f4_adaln(wave_ln(ld4(CT + 768 + 4 * lane), v_csnw, v_csnb, lane), ld4(TTS + 512 + 4 * lane), ld4(TTS + 768 + 4 * lane));
-                    st4(xme + 4 * lane, f4_silu(hh));
+                    put_x<WT, MS>(XB, es, 0, lane, f4_silu(hh));
                 }
             }
             __syncthreads();
             if constexpr (CAQ) {
-                gemv_stream<WT, CAQ, MS, G_CAQ, false>(ring, tid, wg, mo, nskip, XB, PART);
+                gemv_stream<WT, CAQ, MS, G_CAQ, false>(ring, tid, wg, mo, nskip, xin, PART);
                 if (epi) {
                     const float4 qv = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_caq_b + 4 * lane));
                     const float mx = seg_reduce<true>(fmaxf(fmaxf(qv.x, qv.y), fmaxf(qv.z, qv.w)), seg);
@@ -566,43 +675,43 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                             y = f4_fma(dot, ld4(CT + j * 1024 + 768 + 4 * lane), y);                       // (q k^T) v  (:236-237)
                         }
                     const float4 hh = f4_adaln(wave_ln(y, v_csnw, v_csnb, lane), ld4(TTS + 512 + 4 * lane), ld4(TTS + 768 + 4 * lane));
-                    st4(xme + 4 * lane, f4_silu(hh));
+                    put_x<WT, MS>(XB, es, 0, lane, f4_silu(hh));
                 }
                 __syncthreads();
             }
             // ---- proj_out.out_layers + residual
-            gemv_stream<WT, CAQ, MS, G_CAO, false>(ring, tid, wg, mo, nskip, XB, PART);
+            gemv_stream<WT, CAQ, MS, G_CAO, false>(ring, tid, wg, mo, nskip, xin, PART);
             if (epi) {
                 xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_cao_b + 4 * lane)));
-                st4(xme + 4 * lane, xr);
+                put_x<WT, MS>(XB, es, 0, lane, xr);
             }
             __syncthreads();
             // ---- ffn.linear1 + gelu  (N = 128, four k-slices: lanes 0..31 hold 4 outputs each)
-            gemv_stream<WT, CAQ, MS, G_F1, false>(ring, tid, wg, mo, nskip, XB, PART);
+            gemv_stream<WT, CAQ, MS, G_F1, false>(ring, tid, wg, mo, nskip, xin, PART);
             if (epi && lane < FF_D / 4) {
-                const float4 g = f4_add(part_sum<MS, GS<WT, G_F1>::KS, FF_D>(PART, es, 0, lane), ld4(v_f1b + 4 * lane));
-                st4(xme + 4 * lane, make_float4(act_apply(g.x, SEEME_ACT_GELU), act_apply(g.y, SEEME_ACT_GELU),
+                const float4 g = f4_add(gemv_out<WT, MS, G_F1>(PART, es, 0, lane), ld4(v_f1b + 4 * lane));
+                put_x<WT, MS>(XB, es, 0, lane, make_float4(act_apply(g.x, SEEME_ACT_GELU), act_apply(g.y, SEEME_ACT_GELU),
                                                 act_apply(g.z, SEEME_ACT_GELU), act_apply(g.w, SEEME_ACT_GELU)));
             }
             __syncthreads();
             // ---- ffn.linear2 -> AdaLN
-            gemv_stream<WT, CAQ, MS, G_F2, false>(ring, tid, wg, mo, nskip, XB, PART);
+            gemv_stream<WT, CAQ, MS, G_F2, false>(ring, tid, wg, mo, nskip, xin, PART);
             if (epi) {
                 const float4 y2 = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_f2b + 4 * lane));
                 const float4 hh = f4_adaln(wave_ln(y2, v_fsnw, v_fsnb, lane), ld4(TTS + 1024 + 4 * lane), ld4(TTS + 1280 + 4 * lane));
-                st4(xme + 4 * lane, f4_silu(hh));
+                put_x<WT, MS>(XB, es, 0, lane, f4_silu(hh));
             }
             __syncthreads();
             // ---- ffn.proj_out.out_layers + residual; its epilogue also prepares the input of the next layer
             //      (or, after the last layer, runs the stack norm and the scheduler step)
-            gemv_stream<WT, CAQ, MS, G_FO, true>(ring, tid, wg, mo, nskip, XB, PART);
+            gemv_stream<WT, CAQ, MS, G_FO, true>(ring, tid, wg, mo, nskip, xin, PART);
             if (l + 1 < SEEME_DEN_NL) {
                 if (epi) {
                     xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_fo_b + 4 * lane)));
                     if (l == 0) sk0 = xr;
                     if (l == 1) sk1 = xr;
-                    st4(xme + 4 * lane, xr);
-                    if (nskip) st4(xme + 256 + 4 * lane, ln == 3 ? sk1 : sk0);
+                    put_x<WT, MS>(XB, es, 0, lane, xr);
+                    if (nskip) put_x<WT, MS>(XB, es, 256, lane, ln == 3 ? sk1 : sk0);
                 }
                 __syncthreads();
             } else {
@@ -642,7 +751,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                     lat = make_float4(o[0], o[1], o[2], o[3]);
                     xr = f4_add(lat, ld4(CONSTV + 4 * lane));                        // next step: sample + query_pos
                     sk0 = xr; sk1 = xr;
-                    st4(xme + 4 * lane, xr);
+                    put_x<WT, MS>(XB, es, 0, lane, xr);
                 }
                 __syncthreads();
             }
@@ -656,13 +765,13 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     for (int s = 0; s < DEN_R; ++s) asm volatile("" ::"v"(ring.r[s][0].x));
 }
 
-static size_t den_lds_bytes(int MS, int N) {
-    return (size_t)(768 + 2 * (VP_LAYER + STG_TT + MS * N * 1024) + MS * XB_LD + 4 * MS * 768) * sizeof(float);
+static size_t den_lds_bytes(int MS, int N, bool mfma) {
+    return (size_t)(768 + 2 * (VP_LAYER + STG_TT + MS * N * 1024) + XB_FLOATS(mfma, MS) + (mfma ? MS * 1024 : 4 * MS * 768)) * sizeof(float);
 }
 
 template <typename WT, int MS, bool CAQ>
 static int launch_den(const DenKArgs& ka, hipStream_t st) {
-    const size_t lds = den_lds_bytes(MS, ka.s.N);
+    const size_t lds = den_lds_bytes(MS, ka.s.N, WT::MFMA);
     if (lds > 160 * 1024) return seeme_fail("denoiser_sample: LDS budget exceeded");
     SEEME_HIP(hipFuncSetAttribute((const void*)k_den_sample<WT, MS, CAQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_den_sample<WT, MS, CAQ>), dim3(ka.s.B), dim3(DEN_THREADS), lds, st, ka);

@@ -4,8 +4,9 @@
 // with these offsets; seeme_amd/_pack.py asks the library for them and packs the state_dict
 // accordingly.  Order = order of use inside one denoiser step, so the weight stream is sequential.
 //
-// wg offsets are in ELEMENTS of the weight dtype (fp32 or bf16); a PyTorch [N,K] matrix is stored
-// in "GEMV layout" [K/KV][N][KV], KV = 4 (fp32) / 8 (bf16).  vp offsets are in floats.
+// wg offsets are in ELEMENTS of the weight dtype; a PyTorch [N,K] fp32 matrix is stored
+// in "GEMV layout" [K/KV][N][KV], KV = 4; a bf16 / fp16 matrix as the per-wave matrix-core operand
+// stream [wave 8][k-block K/32][tile N/128][lane 64][8] (seeme_amd/mld_denoiser.py put_w).  vp offsets are in floats.
 #pragma once
 #include <stdint.h>
 

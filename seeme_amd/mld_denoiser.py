@@ -178,9 +178,17 @@ class MldDenoiser(nn.Module):
         wg = torch.zeros(wg_total, dtype=wdt, device=dev)
         vp = torch.zeros(vp_total, dtype=torch.float32, device=dev)
 
-        def put_w(off, W):   # PyTorch [N,K] -> GEMV layout [K/KV][N][KV]
+        def put_w(off, W):
             N, K = W.shape
-            g = W.detach().reshape(N, K // KV, KV).permute(1, 0, 2).reshape(-1)
+            if bf16:
+                # matrix-core stream (den_kernels.hip, GS::TW / KB): wave w owns output tiles w*TW .. w*TW+TW-1 (16
+                # outputs each) for all k; wave-load i = (k-block i // TW, tile i % TW); lane = 16*(k-group) + output
+                # row holds 8 consecutive k -- the v_mfma_f32_16x16x32 operand layout
+                TW, KB = N // 128, K // 32
+                g = W.detach().reshape(8, TW, 16, KB, 4, 8).permute(0, 3, 1, 4, 2, 5).reshape(-1)
+            else:
+                # vector-ALU stream: [K/KV][N][KV] 16-byte vectors
+                g = W.detach().reshape(N, K // KV, KV).permute(1, 0, 2).reshape(-1)
             wg[off:off + g.numel()] = g.to(wg.dtype)
 
         def put_v(off, v):
