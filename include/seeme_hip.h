@@ -123,10 +123,13 @@ int seeme_vae_decode(const SeemeVaeWeights* w, const float* z, const int32_t* le
  * mdiff_transformer.py:257-304) and MLD._diffusion_reverse (mld/models/modeltype/mld.py:432-511).
  *
  * Weight image: the host packs the state_dict once into
- *   wg : GEMV-layout matrices, element type fp32, bf16 or fp16 (wdtype 0 / 1 / 2); a [N,K] PyTorch matrix is
- *        stored as [K/KV][N][KV] with KV = 4 (fp32) or 8 (16-bit) so that a wave reads 1 KiB contiguous;
+ *   wg : the matrices in stream order, element type fp32, bf16 or fp16 (wdtype 0 / 1 / 2); a [N,K] PyTorch
+ *        matrix is stored as [K/4][N][4] (fp32, vector-ALU path) or as the per-wave matrix-core operand stream
+ *        [wave 8][K/32][N/128][lane 64][8] (16-bit), so that every wave-load is 1 KiB contiguous;
  *   vp : fp32 vectors (biases, LayerNorm params, pe row 0);
  * in the order documented in seeme_amd/csrc/den_layout.h; seeme_den_layout() exports the offsets.
+ * sa_fold = 1 (one attention head): the image's in_proj V rows / bias and kv_cat_w / kv_cat_b V rows hold
+ * W_o W_v and W_o b_v + b_o instead of W_v, b_v, and the out_proj slot is unused (seeme_amd/mld_denoiser.py).
  */
 typedef struct {
     const void*  wg;   int wdtype;       /* 0 = fp32, 1 = bf16, 2 = fp16 */
@@ -145,6 +148,10 @@ typedef struct {
      * bias W_l tn_b_l + b_l; applied to the affine-free LayerNorm of the condition (ln_ones / ln_zeros) */
     const float* ca_fold_w; const float* ca_fold_b;
     const float* ln_ones; const float* ln_zeros;                                /* [256] each */
+    int sa_fold;                                                                /* 1: out_proj folded into V (nhead == 1) */
+    /* ca_block.proj_out of each layer (StylizationBlock, mdiff_transformer.py:152-163), for seeme_denoiser_ca_tables */
+    const float* ca_pn_w[SEEME_NLAYERS]; const float* ca_pn_b[SEEME_NLAYERS];   /* proj_out.norm [256] */
+    const float* ca_po_w[SEEME_NLAYERS]; const float* ca_po_b[SEEME_NLAYERS];   /* proj_out.out_layers.2 [256,256], [256] */
 } SeemeDenoiserWeights;
 
 /* per-row time tables: floats per row = 5*512 (sa K|V of the time token) + 5*1024 (AdaLN scale|shift, ca|ffn) */
@@ -165,6 +172,16 @@ int seeme_denoiser_time_tables(const SeemeDenoiserWeights* w, const float* tfeat
 int seeme_denoiser_cond_tables(const SeemeDenoiserWeights* w, const float* cond, int Bc, int N,
                                float* ctab, void* workspace, size_t ws_bytes, void* stream);
 
+/* ONE condition token (N == 1): the ca_block's contribution does not depend on the latent (the key softmax over
+ * a single token is 1, mdiff_transformer.py:231-237), so it is tabulated per (sample, table row, layer):
+ *   catab[bc][r][l] = proj_out.out_layers( SiLU( LN(value_l(cond_bc)) * (1 + scale_{row,l}) + shift_{row,l} ) )
+ * with row = trow[r] (trow_per_sample 0, R = n_rows rows per sample) or trow[bc % n_b] (trow_per_sample 1, R = 1,
+ * n_b = number of trow entries).  ctab [Bc,1,SEEME_CROW]; catab [Bc,R,5,256].
+ * workspace >= Bc*R*256 floats. */
+int seeme_denoiser_ca_tables(const SeemeDenoiserWeights* w, const float* ctab, const float* ttab, const int32_t* trow,
+                             int trow_per_sample, int n_trow, int Bc, float* catab,
+                             void* workspace, size_t ws_bytes, void* stream);
+
 typedef struct {
     int B;                 /* samples (latents rows) */
     int N;                 /* condition tokens per sample */
@@ -180,6 +197,7 @@ typedef struct {
     const float* coef;     /* [steps,8] scheduler scalars per step (see seeme_amd/schedulers.py) */
     const float* noise;    /* optional [steps,B,256] step noise (eta>0 / DDPM), NULL otherwise */
     float* out;            /* [B,256] */
+    const float* catab;    /* N == 1: [B or 2B, R, 5, 256] from seeme_denoiser_ca_tables (R = steps, or 1 with trow_per_sample) */
 } SeemeSampleArgs;
 
 int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeSampleArgs* a, void* stream);

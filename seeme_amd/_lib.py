@@ -76,13 +76,14 @@ class DenoiserWeights(C.Structure):
                 ("time_w1", fp), ("time_b1", fp), ("time_w2", fp), ("time_b2", fp),
                 ("ca_kv_w", fp * NLAYERS), ("ca_kv_b", fp * NLAYERS),
                 ("ca_tn_w", fp * NLAYERS), ("ca_tn_b", fp * NLAYERS),
-                ("ca_fold_w", fp), ("ca_fold_b", fp), ("ln_ones", fp), ("ln_zeros", fp)]
+                ("ca_fold_w", fp), ("ca_fold_b", fp), ("ln_ones", fp), ("ln_zeros", fp), ("sa_fold", C.c_int),
+                ("ca_pn_w", fp * NLAYERS), ("ca_pn_b", fp * NLAYERS), ("ca_po_w", fp * NLAYERS), ("ca_po_b", fp * NLAYERS)]
 
 
 class SampleArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("N", C.c_int), ("steps", C.c_int), ("sched", C.c_int), ("cfg", C.c_int),
                 ("guidance_scale", C.c_float), ("latents", fp), ("ctab", fp), ("ttab", fp), ("trow", fp),
-                ("trow_per_sample", C.c_int), ("coef", fp), ("noise", fp), ("out", fp)]
+                ("trow_per_sample", C.c_int), ("coef", fp), ("noise", fp), ("out", fp), ("catab", fp)]
 
 
 class SmplModel(C.Structure):
@@ -113,6 +114,7 @@ _SIGNATURES = {
     "seeme_denoiser_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "seeme_denoiser_time_tables": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, fp, fp, C.c_size_t, fp]),
     "seeme_denoiser_cond_tables": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
+    "seeme_denoiser_ca_tables": (C.c_int, [C.POINTER(DenoiserWeights), fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
     "seeme_denoiser_sample": (C.c_int, [C.POINTER(DenoiserWeights), C.POINTER(SampleArgs), fp]),
     "seeme_den_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "seeme_geometry": (C.c_int, [C.c_int, fp, fp, C.c_int, fp]),

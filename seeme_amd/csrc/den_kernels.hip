@@ -76,16 +76,32 @@ struct GS {
     }
 };
 
-// One layer streams P0 = inp, outp, l1, l2, [caq,] cao, f1, f2, fo (chunk indices 0 .. SUM-1, padded with
+// Kernel variants (template parameter V):
+//   V_CAQ  -- more than one condition token: the linear cross-attention needs its query GEMV and proj_out GEMV.
+//             With ONE token the key softmax over tokens is exactly 1 and the query softmax sums to 1 per head, so
+//             q (k^T v) = v whatever the query is (mdiff_transformer.py:231-237): the ca_block's contribution no
+//             longer depends on x and comes from a precomputed table (seeme_denoiser_ca_tables).
+//   V_FOLD -- one attention head: out_proj is folded into the value projection (W_o W_v, softmax weights sum to
+//             1 so the bias folds too); in_proj then yields q | k | W_o v and the out_proj GEMV disappears.
+#define V_CAQ 1
+#define V_FOLD 2
+// One layer streams P0 = inp, [outp,] l1, l2, [caq, cao,] f1, f2, fo (chunk indices 0 .. SUM-1, padded with
 // no-op chunks to a multiple of the ring size so that chunk t always lives in ring slot t % DEN_R);
 // layers 3 and 4 stream the skip linear first (its chunk count is a multiple of DEN_R too).
-template <typename WT, bool CAQ>
+template <typename WT, int V>
 struct Prog {
-    static constexpr int NG = CAQ ? 9 : 8;
+    static constexpr bool CAQ = (V & V_CAQ) != 0, FOLD = (V & V_FOLD) != 0;
+    static constexpr int NG = 6 + (CAQ ? 2 : 0) + (FOLD ? 0 : 1);
     static constexpr int gid(int i) {
-        constexpr int a[9] = {G_INP, G_OUTP, G_L1, G_L2, G_CAQ, G_CAO, G_F1, G_F2, G_FO};
-        constexpr int b[9] = {G_INP, G_OUTP, G_L1, G_L2, G_CAO, G_F1, G_F2, G_FO, G_FO};
-        return CAQ ? a[i] : b[i];
+        constexpr int all[9] = {G_INP, G_OUTP, G_L1, G_L2, G_CAQ, G_CAO, G_F1, G_F2, G_FO};
+        int k = 0;
+        for (int j = 0; j < 9; ++j) {
+            const int g = all[j];
+            if ((g == G_OUTP && FOLD) || ((g == G_CAQ || g == G_CAO) && !CAQ)) continue;
+            if (k == i) return g;
+            ++k;
+        }
+        return G_FO;
     }
     static constexpr int tot(int g) {
         switch (g) {
@@ -143,20 +159,20 @@ __device__ __forceinline__ MatOffs load_mat_offs(const DenLayerOff* __restrict__
 }
 
 // chunk T of P0 of the current layer
-template <typename WT, bool CAQ, int T>
+template <typename WT, int V, int T>
 __device__ __forceinline__ void issue_p0(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo) {
-    typedef Prog<WT, CAQ> P;
+    typedef Prog<WT, V> P;
     static_assert(T >= 0 && T < P::SUM, "chunk outside the layer program");
     constexpr int i = P::find(T), g = P::gid(i), c = T - P::start(i);
     issue_mat<WT, g, c>(ring.r[T % DEN_R], tid, rsrc, mo.m[g]);
 }
 // chunk T counted from the start of the current layer's P0; T >= P::T addresses the next layer, whose stream
 // starts with its skip linear when nskip is set and with in_proj otherwise (mo.next either way)
-template <typename WT, bool CAQ, int T>
+template <typename WT, int V, int T>
 __device__ __forceinline__ void issue_rel(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip) {
-    typedef Prog<WT, CAQ> P;
+    typedef Prog<WT, V> P;
     if constexpr (T < P::SUM) {
-        issue_p0<WT, CAQ, T>(ring, tid, rsrc, mo);
+        issue_p0<WT, V, T>(ring, tid, rsrc, mo);
     } else if constexpr (T >= P::T) {
         constexpr int j = T - P::T;
         static_assert(j < DEN_R && j < GS<WT, G_INP>::TOT && j < P::TS, "prefetch reaches too far into the next layer");
@@ -254,13 +270,13 @@ struct Acc {
 // layer's P0 (negative for the skip linear), C = local chunk, NC = chunks incl. padding.  Consuming chunk t
 // frees ring slot t % DEN_R, which is re-filled with chunk t + DEN_R -- at once, except for the last BURST
 // chunks of the GEMV, whose re-fill is withheld until the epilogue runs (gemv_stream).
-template <typename WT, bool CAQ, int G, int REL0, int C>
+template <typename WT, int V, int G, int REL0, int C>
 __device__ __forceinline__ void refill(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip) {
     constexpr int TGT = REL0 + C + DEN_R;
-    if constexpr (TGT < 0) issue_mat<WT, G_SKIP, TGT + Prog<WT, CAQ>::TS>(ring.r[((TGT % DEN_R) + DEN_R) % DEN_R], tid, rsrc, mo.m[G_SKIP]);
-    else issue_rel<WT, CAQ, TGT>(ring, tid, rsrc, mo, nskip);
+    if constexpr (TGT < 0) issue_mat<WT, G_SKIP, TGT + Prog<WT, V>::TS>(ring.r[((TGT % DEN_R) + DEN_R) % DEN_R], tid, rsrc, mo.m[G_SKIP]);
+    else issue_rel<WT, V, TGT>(ring, tid, rsrc, mo, nskip);
 }
-template <typename WT, bool CAQ, int MS, int G, int REL0, int NC, int BURST, int C>
+template <typename WT, int V, int MS, int G, int REL0, int NC, int BURST, int C>
 __device__ __forceinline__ void gemv_chunk(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip,
                                            const XIn& x, float* __restrict__ part, Acc<WT, MS, G>& acc) {
     typedef GS<WT, G> S;
@@ -309,35 +325,35 @@ __device__ __forceinline__ void gemv_chunk(Ring& ring, int tid, __amdgpu_buffer_
     }
     acc.pin();
     if constexpr (C < NC - BURST) {
-        refill<WT, CAQ, G, REL0, C>(ring, tid, rsrc, mo, nskip);
+        refill<WT, V, G, REL0, C>(ring, tid, rsrc, mo, nskip);
         acc.pin();
     }
 }
-template <typename WT, bool CAQ, int MS, int G, int REL0, int NC, int BURST, int... Cs>
+template <typename WT, int V, int MS, int G, int REL0, int NC, int BURST, int... Cs>
 __device__ __forceinline__ void gemv_chunks(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip,
                                             const XIn& x, float* __restrict__ part, Acc<WT, MS, G>& acc,
                                             std::integer_sequence<int, Cs...>) {
-    (gemv_chunk<WT, CAQ, MS, G, REL0, NC, BURST, Cs>(ring, tid, rsrc, mo, nskip, x, part, acc), ...);
+    (gemv_chunk<WT, V, MS, G, REL0, NC, BURST, Cs>(ring, tid, rsrc, mo, nskip, x, part, acc), ...);
 }
 
 // Streaming half of GEMV G: every wave consumes its chunks (ring slots were requested earlier), publishes the
 // partial sums (barrier A) and then requests the withheld chunks, which keeps the L1 fill path busy while the
 // epilogue wave(s) turn the partial sums into the next GEMV's input.  The caller runs the epilogue and then
 // barrier B.  On entry and exit DEN_R chunks are in flight ahead of the consumer.
-template <typename WT, bool CAQ, int MS, int G, bool LAST>
+template <typename WT, int V, int MS, int G, bool LAST>
 __device__ __forceinline__ void gemv_stream(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip,
                                             const XIn& x, float* __restrict__ part) {
-    typedef Prog<WT, CAQ> P;
+    typedef Prog<WT, V> P;
     constexpr int REL0 = (G == G_SKIP) ? -P::TS : P::start(P::pos(G));
     constexpr int NC = GS<WT, G>::TOT + (LAST ? P::PAD : 0);
     constexpr int BURST = NC < 2 ? NC : 2;
     asm volatile("" : "+v"(tid));   // addresses are recomputed per GEMV, not kept live across the layer body
     Acc<WT, MS, G> acc;
     acc.zero();
-    gemv_chunks<WT, CAQ, MS, G, REL0, NC, BURST>(ring, tid, rsrc, mo, nskip, x, part, acc, std::make_integer_sequence<int, NC>{});
+    gemv_chunks<WT, V, MS, G, REL0, NC, BURST>(ring, tid, rsrc, mo, nskip, x, part, acc, std::make_integer_sequence<int, NC>{});
     __syncthreads();                                                  // barrier A: partial sums visible
-    refill<WT, CAQ, G, REL0, NC - BURST>(ring, tid, rsrc, mo, nskip);
-    if constexpr (BURST == 2) refill<WT, CAQ, G, REL0, NC - 1>(ring, tid, rsrc, mo, nskip);
+    refill<WT, V, G, REL0, NC - BURST>(ring, tid, rsrc, mo, nskip);
+    if constexpr (BURST == 2) refill<WT, V, G, REL0, NC - 1>(ring, tid, rsrc, mo, nskip);
     acc.pin();
 }
 
@@ -445,12 +461,13 @@ struct DenKArgs {
 // over the 8 waves.  vmcnt retires in issue order, so once a wave has consumed any weight chunk it requested
 // later, its copies have landed; the barriers of layer l then publish them.  (hipcc does not count the asm
 // DMA: its own vmcnt(N) waits only become slightly longer, never shorter.)
-template <int MS>
+template <int MS, bool CAQ>
 __device__ __forceinline__ void stage_dma(int wave, int lane, float* __restrict__ stg, const float* __restrict__ vpg,
                                           const DenLayerOff* __restrict__ L, const float* __restrict__ tt_row, int l,
-                                          const SeemeSampleArgs& A, int b, int N) {
+                                          const SeemeSampleArgs& A, int b, int N, int ca_r, int ca_R) {
     const uint32_t base = lds_addr_of(stg);
-    const int total = 31 + 4 * MS * N;
+    const int ncond = 31 + 4 * MS * N;
+    const int total = ncond + (CAQ ? 0 : MS);
 #pragma unroll 1
     for (int c = wave; c < total; c += DEN_THREADS / 64) {
         const float* src;
@@ -461,6 +478,10 @@ __device__ __forceinline__ void stage_dma(int wave, int lane, float* __restrict_
             src = tt_row + l * 512 + (c - 25) * 256; dst = VP_LAYER + (c - 25) * 256;
         } else if (c < 31) {                // AdaLN scale|shift rows (ca, ffn)
             src = tt_row + 2560 + l * 1024 + (c - 27) * 256; dst = VP_LAYER + 512 + (c - 27) * 256;
+        } else if (!CAQ && c >= ncond) {    // one condition token: the tabulated ca_block term of (sample, row, layer)
+            const int sidx = c - ncond;
+            const int bc = (MS == 2 && sidx == 1) ? A.B + b : b;
+            src = A.catab + (((size_t)bc * ca_R + ca_r) * SEEME_DEN_NL + l) * 256; dst = VP_LAYER + STG_TT + MS * N * 1024 + sidx * 256;
         } else {                            // condition tokens: sa K|V (512) | ca key|value (512) per (sample, token)
             const int j = c - 31, sn = j >> 2, q = j & 3;
             const int s = sn / N, n = sn - s * N;
@@ -472,10 +493,11 @@ __device__ __forceinline__ void stage_dma(int wave, int lane, float* __restrict_
     }
 }
 
-template <typename WT, int MS, bool CAQ>
+template <typename WT, int MS, int V>
 __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    typedef Prog<WT, CAQ> P;
+    typedef Prog<WT, V> P;
+    constexpr bool CAQ = P::CAQ, FOLD = P::FOLD;
     // wave-uniform buffer descriptor of the packed weight image (raw buffer loads: VGPR offset + SGPR offset)
     const __amdgpu_buffer_rsrc_t wg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ka.wg), 0, ka.wg_bytes, 0x00020000);
     const float* __restrict__ vp = ka.vp;
@@ -492,7 +514,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     const bool epi = wave < MS;                  // wave s turns sample s's partial sums into the next input vector
 #endif
     const int es = epi ? wave : 0;
-    const int stg_sz = VP_LAYER + STG_TT + MS * N * 1024;
+    const int stg_sz = VP_LAYER + STG_TT + MS * N * 1024 + (CAQ ? 0 : MS * 256);
+    const int ca_R = A.trow_per_sample ? 1 : A.steps;
 
     float* CONSTV = smem;                        // [768]            query_pos.pe[0], encoder.norm.{weight,bias}
     float* STG = CONSTV + 768;                   // [2][stg_sz]      per-layer operands, double-buffered
@@ -518,7 +541,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     {
         for (int i = tid0; i < 192; i += DEN_THREADS)
             st4(CONSTV + 4 * i, i < 64 ? ld4(vp + lay->pe0 + 4 * i) : (i < 128 ? ld4(vp + lay->fnw + 4 * (i - 64)) : ld4(vp + lay->fnb + 4 * (i - 128))));
-        stage_dma<MS>(wave, lane, STG, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b, N);
+        stage_dma<MS, CAQ>(wave, lane, STG, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b, N, 0, ca_R);
         if (WT::MFMA) for (int i = tid0; i < XB_FLOATS(true, MS) / 4; i += DEN_THREADS) st4(XB + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
         wait_vmcnt0();
         __syncthreads();
@@ -527,8 +550,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     Ring ring;
     {
         const MatOffs m0 = load_mat_offs<WT>(&lay->L[0], &lay->L[1], false);
-        issue_p0<WT, CAQ, 0>(ring, tid0, wg, m0); issue_p0<WT, CAQ, 1>(ring, tid0, wg, m0);
-        issue_p0<WT, CAQ, 2>(ring, tid0, wg, m0); issue_p0<WT, CAQ, 3>(ring, tid0, wg, m0);
+        issue_p0<WT, V, 0>(ring, tid0, wg, m0); issue_p0<WT, V, 1>(ring, tid0, wg, m0);
+        issue_p0<WT, V, 2>(ring, tid0, wg, m0); issue_p0<WT, V, 3>(ring, tid0, wg, m0);
         static_assert(DEN_R == 4, "prologue issues four chunks");
     }
     __syncthreads();
@@ -537,7 +560,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
 #pragma unroll 1
     for (int step = 0; step < A.steps; ++step) {
         // table row of the NEXT step (the last layer stages layer 0 of the next step)
-        const int row_next = A.trow_per_sample ? row : A.trow[step + 1 < A.steps ? step + 1 : step];
+        const int step_next = step + 1 < A.steps ? step + 1 : step;
+        const int row_next = A.trow_per_sample ? row : A.trow[step_next];
 #pragma unroll 1
         for (int l = 0; l < SEEME_DEN_NL; ++l) {
             const DenLayerOff* __restrict__ L = &lay->L[l];
@@ -553,8 +577,10 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             const float* TTS = VP + VP_LAYER;                // time-token K|V (512) + AdaLN rows (1024)
             const float* CTS = TTS + STG_TT;                 // [MS][N][1024] condition K|V (sa 512 | ca 512)
             const float* CT = CTS + es * N * 1024;
+            const float* CA_ADD = CTS + MS * N * 1024 + es * 256;   // (one condition token) tabulated ca_block term
             // request the next layer's operands (LDS-DMA into the other half of the double buffer)
-            stage_dma<MS>(wave, lane, STG + (cur ^ 1) * stg_sz, vp, Ln, A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW, ln, A, b, N);
+            stage_dma<MS, CAQ>(wave, lane, STG + (cur ^ 1) * stg_sz, vp, Ln, A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW, ln, A, b, N,
+                                A.trow_per_sample ? 0 : (ln == 0 ? step_next : step), ca_R);
             // offsets inside VP (relative to skip_b)
             const float* v_skip_b = VP;
             const float* v_in_b = VP + (L->in_b - L->skip_b);
@@ -573,7 +599,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             // ---- skip connection: Linear(cat[x, xs.pop()])  (cross_attention.py:77-79); input staged by the
             //      previous layer's last epilogue
             if (l >= 3) {
-                gemv_stream<WT, CAQ, MS, G_SKIP, false>(ring, tid, wg, mo, nskip, xin, PART);
+                gemv_stream<WT, V, MS, G_SKIP, false>(ring, tid, wg, mo, nskip, xin, PART);
                 if (epi) {
                     xr = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_skip_b + 4 * lane));
                     put_x<WT, MS>(XB, es, 0, lane, xr);
@@ -582,7 +608,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             }
             // ---- sa_block: post-norm encoder layer over [x, xf.., emb]; only token 0 is kept
             //      (mdiff_transformer.py:292-297); K/V of xf and emb come from the tables.
-            gemv_stream<WT, CAQ, MS, G_INP, false>(ring, tid, wg, mo, nskip, xin, PART);
+            gemv_stream<WT, V, MS, G_INP, false>(ring, tid, wg, mo, nskip, xin, PART);
             if (epi) {
                 // in_proj output n in [0,768): q | k | v
                 const float4 q = f4_add(gemv_out<WT, MS, G_INP>(PART, es, 0, lane), ld4(v_in_b + 4 * lane));
@@ -606,19 +632,26 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                 for (int j = 0; j < DEN_MAXTOK - 2; ++j)
                     if (j < N) att = f4_fma(sc[1 + j] * inv, ld4(CT + j * 1024 + 256 + 4 * lane), att);
                 att = f4_fma(et * inv, ld4(TTS + 256 + 4 * lane), att);
-                put_x<WT, MS>(XB, es, 0, lane, att);
+                if constexpr (FOLD) {   // the "values" already carry out_proj: residual + norm1 right here
+                    xr = wave_ln(f4_add(xr, att), v_n1w, v_n1b, lane);
+                    put_x<WT, MS>(XB, es, 0, lane, xr);
+                } else {
+                    put_x<WT, MS>(XB, es, 0, lane, att);
+                }
             }
             __syncthreads();
-            // ---- out_proj + residual + norm1
-            gemv_stream<WT, CAQ, MS, G_OUTP, false>(ring, tid, wg, mo, nskip, xin, PART);
-            if (epi) {
-                const float4 v = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_out_b + 4 * lane)));
-                xr = wave_ln(v, v_n1w, v_n1b, lane);
-                put_x<WT, MS>(XB, es, 0, lane, xr);
+            if constexpr (!FOLD) {
+                // ---- out_proj + residual + norm1
+                gemv_stream<WT, V, MS, G_OUTP, false>(ring, tid, wg, mo, nskip, xin, PART);
+                if (epi) {
+                    const float4 v = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_out_b + 4 * lane)));
+                    xr = wave_ln(v, v_n1w, v_n1b, lane);
+                    put_x<WT, MS>(XB, es, 0, lane, xr);
+                }
+                __syncthreads();
             }
-            __syncthreads();
             // ---- linear1 + relu  (N = 1024, one k-slice)
-            gemv_stream<WT, CAQ, MS, G_L1, false>(ring, tid, wg, mo, nskip, xin, PART);
+            gemv_stream<WT, V, MS, G_L1, false>(ring, tid, wg, mo, nskip, xin, PART);
             if (epi) {
 #pragma unroll
                 for (int j = 0; j < FF_SA / 256; ++j) {
@@ -628,22 +661,21 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             }
             __syncthreads();
             // ---- linear2 + residual + norm2, then ca_block (mdiff_transformer.py:219-239, 152-163)
-            gemv_stream<WT, CAQ, MS, G_L2, false>(ring, tid, wg, mo, nskip, xin, PART);
+            gemv_stream<WT, V, MS, G_L2, false>(ring, tid, wg, mo, nskip, xin, PART);
             if (epi) {
                 const float4 v = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_l2b + 4 * lane)));
                 xr = wave_ln(v, v_n2w, v_n2b, lane);
                 if constexpr (CAQ) {
                     put_x<WT, MS>(XB, es, 0, lane, wave_ln(xr, v_cnw, v_cnb, lane));          // ca_block.norm -> query input
                 } else {
-                    // ONE condition token: the key softmax over tokens is exactly 1 and the query softmax sums to 1
-                    // per head, so q (k^T v) = v whatever the query is (:231-237) -- the query GEMV is skipped.
-                    const float4 hh = f4_adaln(wave_ln(ld4(CT + 768 + 4 * lane), v_csnw, v_csnb, lane), ld4(TTS + 512 + 4 * lane), ld4(TTS + 768 + 4 * lane));
-                    put_x<WT, MS>(XB, es, 0, lane, f4_silu(hh));
+                    // ONE condition token: x + Stylization(v) with a term that does not depend on x (table)
+                    xr = f4_add(xr, ld4(CA_ADD + 4 * lane));
+                    put_x<WT, MS>(XB, es, 0, lane, xr);
                 }
             }
             __syncthreads();
             if constexpr (CAQ) {
-                gemv_stream<WT, CAQ, MS, G_CAQ, false>(ring, tid, wg, mo, nskip, xin, PART);
+                gemv_stream<WT, V, MS, G_CAQ, false>(ring, tid, wg, mo, nskip, xin, PART);
                 if (epi) {
                     const float4 qv = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_caq_b + 4 * lane));
                     const float mx = seg_reduce<true>(fmaxf(fmaxf(qv.x, qv.y), fmaxf(qv.z, qv.w)), seg);
@@ -678,16 +710,16 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                     put_x<WT, MS>(XB, es, 0, lane, f4_silu(hh));
                 }
                 __syncthreads();
+                // ---- proj_out.out_layers + residual
+                gemv_stream<WT, V, MS, G_CAO, false>(ring, tid, wg, mo, nskip, xin, PART);
+                if (epi) {
+                    xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_cao_b + 4 * lane)));
+                    put_x<WT, MS>(XB, es, 0, lane, xr);
+                }
+                __syncthreads();
             }
-            // ---- proj_out.out_layers + residual
-            gemv_stream<WT, CAQ, MS, G_CAO, false>(ring, tid, wg, mo, nskip, xin, PART);
-            if (epi) {
-                xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_cao_b + 4 * lane)));
-                put_x<WT, MS>(XB, es, 0, lane, xr);
-            }
-            __syncthreads();
             // ---- ffn.linear1 + gelu  (N = 128, four k-slices: lanes 0..31 hold 4 outputs each)
-            gemv_stream<WT, CAQ, MS, G_F1, false>(ring, tid, wg, mo, nskip, xin, PART);
+            gemv_stream<WT, V, MS, G_F1, false>(ring, tid, wg, mo, nskip, xin, PART);
             if (epi && lane < FF_D / 4) {
                 const float4 g = f4_add(gemv_out<WT, MS, G_F1>(PART, es, 0, lane), ld4(v_f1b + 4 * lane));
                 put_x<WT, MS>(XB, es, 0, lane, make_float4(act_apply(g.x, SEEME_ACT_GELU), act_apply(g.y, SEEME_ACT_GELU),
@@ -695,7 +727,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             }
             __syncthreads();
             // ---- ffn.linear2 -> AdaLN
-            gemv_stream<WT, CAQ, MS, G_F2, false>(ring, tid, wg, mo, nskip, xin, PART);
+            gemv_stream<WT, V, MS, G_F2, false>(ring, tid, wg, mo, nskip, xin, PART);
             if (epi) {
                 const float4 y2 = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_f2b + 4 * lane));
                 const float4 hh = f4_adaln(wave_ln(y2, v_fsnw, v_fsnb, lane), ld4(TTS + 1024 + 4 * lane), ld4(TTS + 1280 + 4 * lane));
@@ -704,7 +736,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             __syncthreads();
             // ---- ffn.proj_out.out_layers + residual; its epilogue also prepares the input of the next layer
             //      (or, after the last layer, runs the stack norm and the scheduler step)
-            gemv_stream<WT, CAQ, MS, G_FO, true>(ring, tid, wg, mo, nskip, xin, PART);
+            gemv_stream<WT, V, MS, G_FO, true>(ring, tid, wg, mo, nskip, xin, PART);
             if (l + 1 < SEEME_DEN_NL) {
                 if (epi) {
                     xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_fo_b + 4 * lane)));
@@ -766,22 +798,26 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
 }
 
 static size_t den_lds_bytes(int MS, int N, bool mfma) {
-    return (size_t)(768 + 2 * (VP_LAYER + STG_TT + MS * N * 1024) + XB_FLOATS(mfma, MS) + (mfma ? MS * 1024 : 4 * MS * 768)) * sizeof(float);
+    return (size_t)(768 + 2 * (VP_LAYER + STG_TT + MS * N * 1024 + (N > 1 ? 0 : MS * 256)) + XB_FLOATS(mfma, MS) + (mfma ? MS * 1024 : 4 * MS * 768)) * sizeof(float);
 }
 
-template <typename WT, int MS, bool CAQ>
+template <typename WT, int MS, int V>
 static int launch_den(const DenKArgs& ka, hipStream_t st) {
     const size_t lds = den_lds_bytes(MS, ka.s.N, WT::MFMA);
     if (lds > 160 * 1024) return seeme_fail("denoiser_sample: LDS budget exceeded");
-    SEEME_HIP(hipFuncSetAttribute((const void*)k_den_sample<WT, MS, CAQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_den_sample<WT, MS, CAQ>), dim3(ka.s.B), dim3(DEN_THREADS), lds, st, ka);
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_den_sample<WT, MS, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_den_sample<WT, MS, V>), dim3(ka.s.B), dim3(DEN_THREADS), lds, st, ka);
     return seeme_check_launch("k_den_sample");
 }
-template <typename WT>
-static int launch_den_wt(const DenKArgs& ka, hipStream_t st) {
+template <typename WT, int MS>
+static int launch_den_ms(const DenKArgs& ka, bool fold, hipStream_t st) {
     const bool caq = ka.s.N > 1;
-    if (ka.s.cfg) return caq ? launch_den<WT, 2, true>(ka, st) : launch_den<WT, 2, false>(ka, st);
-    return caq ? launch_den<WT, 1, true>(ka, st) : launch_den<WT, 1, false>(ka, st);
+    if (caq) return fold ? launch_den<WT, MS, V_CAQ | V_FOLD>(ka, st) : launch_den<WT, MS, V_CAQ>(ka, st);
+    return fold ? launch_den<WT, MS, V_FOLD>(ka, st) : launch_den<WT, MS, 0>(ka, st);
+}
+template <typename WT>
+static int launch_den_wt(const DenKArgs& ka, bool fold, hipStream_t st) {
+    return ka.s.cfg ? launch_den_ms<WT, 2>(ka, fold, st) : launch_den_ms<WT, 1>(ka, fold, st);
 }
 
 extern "C" int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeSampleArgs* a, void* stream) {
@@ -800,9 +836,12 @@ extern "C" int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeS
     }
     ka.nhead = w->nhead; ka.s = *a;
     hipStream_t st = (hipStream_t)stream;
-    if (w->wdtype == 0) return launch_den_wt<WF32>(ka, st);
-    if (w->wdtype == 1) return launch_den_wt<WBF16>(ka, st);
-    if (w->wdtype == 2) return launch_den_wt<WF16>(ka, st);
+    const bool fold = w->sa_fold != 0;
+    if (fold && w->nhead != 1) return seeme_fail("denoiser_sample: sa_fold needs nhead == 1");
+    if (a->N == 1 && a->catab == nullptr) return seeme_fail("denoiser_sample: N == 1 needs the ca table (seeme_denoiser_ca_tables)");
+    if (w->wdtype == 0) return launch_den_wt<WF32>(ka, fold, st);
+    if (w->wdtype == 1) return launch_den_wt<WBF16>(ka, fold, st);
+    if (w->wdtype == 2) return launch_den_wt<WF16>(ka, fold, st);
     return seeme_fail("denoiser_sample: wdtype must be 0 (fp32), 1 (bf16) or 2 (fp16)");
 }
 
@@ -854,5 +893,47 @@ extern "C" int seeme_denoiser_cond_tables(const SeemeDenoiserWeights* w, const f
     if (w->ca_fold_w == nullptr) return seeme_fail("cond_tables: folded key/value weights missing");
     if ((rc = seeme_linear_simple(st, cond, 256, w->ca_fold_w, 256, w->ca_fold_b, ctab + 2560, SEEME_CROW, M, 2560, 256, 0, 0,
                                   w->ln_ones, w->ln_zeros))) return rc;
+    return 0;
+}
+
+// ------------------------------------------------------------------ ca_block table for ONE condition token
+// H[(bc*R + r)][256] = SiLU( LN(value_l(cond_bc); proj_out.norm) * (1 + scale) + shift ), one wave per row
+__global__ __launch_bounds__(256) void k_ca_rows(const float* __restrict__ ctab, const float* __restrict__ ttab,
+                                                 const int32_t* __restrict__ trow, int per_sample, int n_trow, int R, int rows, int l,
+                                                 const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ H) {
+    const int lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r0 >= rows) return;
+    const int bc = r0 / R, r = r0 - bc * R;
+    const int row = per_sample ? trow[bc % n_trow] : trow[r];
+    const float4 v = ld4(ctab + (size_t)bc * SEEME_CROW + 2560 + l * 512 + 256 + 4 * lane);
+    const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+    const float4 c = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+    const float rs = 1.f / sqrtf(wave_sum(f4_dot(c, c)) * (1.f / 256.f) + 1e-5f);
+    const float4 wv = ld4(nw + 4 * lane), bv = ld4(nb + 4 * lane);
+    const float4 hn = make_float4(c.x * rs * wv.x + bv.x, c.y * rs * wv.y + bv.y, c.z * rs * wv.z + bv.z, c.w * rs * wv.w + bv.w);
+    const float* tt = ttab + (size_t)row * SEEME_TROW + 2560 + l * 1024;
+    st4(H + (size_t)r0 * 256 + 4 * lane, f4_silu(f4_adaln(hn, ld4(tt + 4 * lane), ld4(tt + 256 + 4 * lane))));
+}
+
+extern "C" int seeme_denoiser_ca_tables(const SeemeDenoiserWeights* w, const float* ctab, const float* ttab, const int32_t* trow,
+                                        int trow_per_sample, int n_trow, int Bc, float* catab,
+                                        void* workspace, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (Bc <= 0 || n_trow <= 0) return seeme_fail("ca_tables: empty batch / row list");
+    const int R = trow_per_sample ? 1 : n_trow;
+    const int rows = Bc * R;
+    if (ws_bytes < (size_t)rows * 256 * sizeof(float)) return seeme_fail("ca_tables: workspace too small");
+    float* H = (float*)workspace;
+    for (int l = 0; l < SEEME_DEN_NL; ++l) {
+        if (w->ca_pn_w[l] == nullptr || w->ca_po_w[l] == nullptr) return seeme_fail("ca_tables: proj_out weights missing");
+        hipLaunchKernelGGL(k_ca_rows, dim3((rows + 3) / 4), dim3(256), 0, st, ctab, ttab, trow, trow_per_sample, n_trow, R, rows, l,
+                           w->ca_pn_w[l], w->ca_pn_b[l], H);
+        int rc = seeme_check_launch("k_ca_rows");
+        if (rc) return rc;
+        // proj_out.out_layers: Linear(256,256) -> catab[:, :, l, :]
+        if ((rc = seeme_linear_simple(st, H, 256, w->ca_po_w[l], 256, w->ca_po_b[l], catab + l * 256, SEEME_DEN_NL * 256, rows, 256, 256,
+                                      0, 0, nullptr, nullptr))) return rc;
+    }
     return 0;
 }

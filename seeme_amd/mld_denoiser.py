@@ -195,7 +195,22 @@ class MldDenoiser(nn.Module):
             vp[off:off + v.numel()] = v.detach().reshape(-1)
 
         blocks = self.encoder.blocks()
+        # One attention head: fold out_proj into the value projection (softmax weights sum to 1, so the bias
+        # folds too): in_proj V rows <- W_o W_v, bias <- W_o b_v + b_o; the out_proj GEMV disappears and the
+        # K|V tables of the condition / time tokens carry W_o v directly (den_kernels.hip, V_FOLD).
+        fold = self.num_heads == 1
+
+        def sa_in_proj(sa):
+            Wi, bi = sa.self_attn.in_proj_weight.detach(), sa.self_attn.in_proj_bias.detach()
+            if not fold:
+                return Wi, bi
+            Wo, bo = sa.self_attn.out_proj.weight.detach().double(), sa.self_attn.out_proj.bias.detach().double()
+            Wu = (Wo @ Wi[512:].double()).float()
+            bu = (Wo @ bi[512:].double() + bo).float()
+            return torch.cat([Wi[:512], Wu]), torch.cat([bi[:512], bu])
+
         with torch.no_grad():
+            in_proj = [sa_in_proj(b.sa_block) for b in blocks]
             put_v(pe0, self.query_pos.pe[0, 0])
             put_v(fnw, self.encoder.norm.weight)
             put_v(fnb, self.encoder.norm.bias)
@@ -204,8 +219,9 @@ class MldDenoiser(nn.Module):
                 if l >= 3:
                     put_w(o["skip"], self.encoder.linear_blocks[l - 3].weight)
                     put_v(o["skip_b"], self.encoder.linear_blocks[l - 3].bias)
-                put_w(o["inp"], sa.self_attn.in_proj_weight); put_v(o["in_b"], sa.self_attn.in_proj_bias)
-                put_w(o["outp"], sa.self_attn.out_proj.weight); put_v(o["out_b"], sa.self_attn.out_proj.bias)
+                put_w(o["inp"], in_proj[l][0]); put_v(o["in_b"], in_proj[l][1])
+                if not fold:
+                    put_w(o["outp"], sa.self_attn.out_proj.weight); put_v(o["out_b"], sa.self_attn.out_proj.bias)
                 put_w(o["l1"], sa.linear1.weight); put_v(o["l1b"], sa.linear1.bias)
                 put_w(o["l2"], sa.linear2.weight); put_v(o["l2b"], sa.linear2.bias)
                 put_v(o["n1w"], sa.norm1.weight); put_v(o["n1b"], sa.norm1.bias)
@@ -218,8 +234,8 @@ class MldDenoiser(nn.Module):
                 put_w(o["f2"], ffn.linear2.weight); put_v(o["f2b"], ffn.linear2.bias)
                 put_v(o["fsnw"], ffn.proj_out.norm.weight); put_v(o["fsnb"], ffn.proj_out.norm.bias)
                 put_w(o["fo"], ffn.proj_out.out_layers[2].weight); put_v(o["fo_b"], ffn.proj_out.out_layers[2].bias)
-            kv_w = torch.cat([b.sa_block.self_attn.in_proj_weight[256:] for b in blocks]).contiguous()
-            kv_b = torch.cat([b.sa_block.self_attn.in_proj_bias[256:] for b in blocks]).contiguous()
+            kv_w = torch.cat([in_proj[l][0][256:] for l in range(len(blocks))]).contiguous()
+            kv_b = torch.cat([in_proj[l][1][256:] for l in range(len(blocks))]).contiguous()
             st_w = torch.cat([torch.cat([b.ca_block.proj_out.emb_layers[1].weight, b.ffn.proj_out.emb_layers[1].weight])
                               for b in blocks]).contiguous()
             st_b = torch.cat([torch.cat([b.ca_block.proj_out.emb_layers[1].bias, b.ffn.proj_out.emb_layers[1].bias])
@@ -241,6 +257,10 @@ class MldDenoiser(nn.Module):
         for l, b in enumerate(blocks):
             w.ca_kv_w[l], w.ca_kv_b[l] = ca_w[l].data_ptr(), ca_b[l].data_ptr()
             w.ca_tn_w[l], w.ca_tn_b[l] = L.ptr(b.ca_block.text_norm.weight), L.ptr(b.ca_block.text_norm.bias)
+            po = b.ca_block.proj_out
+            w.ca_pn_w[l], w.ca_pn_b[l] = L.ptr(po.norm.weight), L.ptr(po.norm.bias)
+            w.ca_po_w[l], w.ca_po_b[l] = L.ptr(po.out_layers[2].weight), L.ptr(po.out_layers[2].bias)
+        w.sa_fold = int(fold)
         w.ca_fold_w, w.ca_fold_b, w.ln_ones, w.ln_zeros = cf_w.data_ptr(), cf_b.data_ptr(), ones.data_ptr(), zeros.data_ptr()
         self._wcache = (fpnt, w, (wg, vp, kv_w, kv_b, st_w, st_b, ca_w, ca_b, lay_dev, cf_w, cf_b, ones, zeros))
         self._table_cache = {}
@@ -277,6 +297,19 @@ class MldDenoiser(nn.Module):
                                                     L.current_stream()), "seeme_denoiser_cond_tables")
         return ctab
 
+    def ca_tables(self, ctab: torch.Tensor, ttab: torch.Tensor, trow: torch.Tensor, per_sample: bool) -> torch.Tensor:
+        """ONE condition token: the ca_block term of every (sample, table row, layer), [Bc,R,5,256] (it does not
+        depend on the latent -- mdiff_transformer.py:231-237 with a single key; include/seeme_hip.h)."""
+        Bc = ctab.shape[0]
+        R = 1 if per_sample else trow.numel()
+        catab = torch.empty(Bc, R, 5, self.latent_dim, device=ctab.device, dtype=torch.float32)
+        ws = torch.empty(Bc * R * 256, device=ctab.device, dtype=torch.float32)
+        w = self._weights()
+        L.check(L.lib().seeme_denoiser_ca_tables(C.byref(w), ctab.data_ptr(), ttab.data_ptr(), trow.data_ptr(), int(per_sample),
+                                                  trow.numel(), Bc, catab.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                                  L.current_stream()), "seeme_denoiser_ca_tables")
+        return catab
+
     def _launch(self, latents2d, ctab, ttab, trow, per_sample, steps, sched, coef, noise, cfg, guidance):
         B, N = latents2d.shape[0], ctab.shape[1]
         out = torch.empty(B, self.latent_dim, device=latents2d.device, dtype=torch.float32)
@@ -284,6 +317,8 @@ class MldDenoiser(nn.Module):
         a.B, a.N, a.steps, a.sched, a.cfg, a.guidance_scale = B, N, steps, sched, int(cfg), float(guidance)
         a.latents, a.ctab, a.ttab, a.trow, a.trow_per_sample = latents2d.data_ptr(), ctab.data_ptr(), ttab.data_ptr(), trow.data_ptr(), int(per_sample)
         a.coef, a.noise, a.out = L.ptr(coef), L.ptr(noise), out.data_ptr()
+        catab = self.ca_tables(ctab, ttab, trow, per_sample) if N == 1 else None
+        a.catab = L.ptr(catab)
         w = self._weights()
         L.check(L.lib().seeme_denoiser_sample(C.byref(w), C.byref(a), L.current_stream()), "seeme_denoiser_sample")
         return out
