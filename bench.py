@@ -58,13 +58,29 @@ def one_pass(vae, den, sch, motion, latents, lengths, ev=None):
     return vae.decode(z, lengths)
 
 
+REF_LIVE_PARAMS = 7_644_288   # the denoiser's 7.64 M live parameters (mem_pos and unused pe rows excluded)
+
+
 def den_algorithmic_bytes(den, B, N, steps):
-    """Bytes one launch of the sampling kernel must touch: per step the packed weight image (read once
-    per step for the whole batch) + the time-table row; per sample the condition tables and the latent."""
-    w = den._weights()
-    keep = den._wcache[2]
-    wg, vp = keep[0], keep[1]
-    per_step = wg.numel() * wg.element_size() + vp.numel() * 4 + 7680 * 4
+    """SURVEY.md section 8(d) per-unit figure x units of one launch: per DDIM step the reference graph's live
+    weights once for the whole batch (15.3 MB at 16 bit, 30.6 MB fp32) + B x (2+N) x 256 activations."""
+    esize = 4 if den.weight_dtype == "fp32" else 2
+    return steps * (REF_LIVE_PARAMS * esize + B * (2 + N) * 256 * esize)
+
+
+def den_executed_bytes(den, B, N, steps):
+    """Bytes the sampling kernel actually streams per launch and workgroup chain: the matrices its program
+    keeps after the exact reductions (token-0 pruning, folded out_proj, tabulated ca term), the per-layer
+    vectors and the table rows, once per step; per sample the condition tables and the latent."""
+    esize = 4 if den.weight_dtype == "fp32" else 2
+    D, FS, FF = 256, 1024, den.ff_size
+    per_layer = 3 * D * D + 2 * FS * D + 2 * FF * D + D * D          # in_proj, linear1/2, ffn.linear1/2, ffn proj_out
+    if den.num_heads != 1:
+        per_layer += D * D                                            # out_proj (not folded)
+    if N > 1:
+        per_layer += 2 * D * D                                        # ca query + proj_out
+    mats = 5 * per_layer + 2 * 2 * D * D                              # + two skip linears
+    per_step = mats * esize + 5 * (6272 + 1536 + (256 if N == 1 else 0)) * 4
     per_sample = N * 5120 * 4 + 2 * 256 * 4
     return steps * per_step + B * per_sample
 
@@ -169,6 +185,9 @@ def main():
     loop_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     alg_bytes = den_algorithmic_bytes(den, B, 1, n_infer)
     achieved = alg_bytes / (loop_ms * 1e-3) / 1e9
+    exe_bytes = den_executed_bytes(den, B, 1, n_infer)
+    cus = min(B, 256)                                   # one workgroup (one CU) per sample chain
+    per_cu = exe_bytes / (loop_ms * 1e-3) / 1e9         # every chain streams the image itself (from L2 / Infinity Cache)
 
     if rank == 0:
         res = {
@@ -192,7 +211,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_den_sample (persistent DDIM loop)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.weights, B, n_infer),
-                         "ms_per_launch": round(loop_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)},
+                         "ms_per_launch": round(loop_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                         # what actually bounds this kernel: each sample chain streams the (reduced) weight image through ONE
+                         # CU's L1 fill path every step; measured ceiling of that path 118 GB/s (scripts/stream_probe3.py)
+                         "executed_bytes_per_launch": int(exe_bytes),
+                         "per_cu_stream": {"achieved": round(per_cu, 2), "peak": 118.0, "unit": "GB/s per CU",
+                                           "frac": round(per_cu / 118.0, 4), "cus_busy": cus}},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(B)

@@ -67,9 +67,13 @@ struct GS {
     static constexpr int TOT = IT * CPI;                                            // chunks per thread
     static_assert(G0 * KS == DEN_THREADS * IT && NQ * KS * WT::KV == K && NQ % 4 == 0 && TOT >= 1, "unsupported GEMV shape");
     // matrix-core mapping (16-bit weights): wave w owns the TW output tiles (16 outputs each) w*TW .. w*TW+TW-1
-    // for ALL k; its stream is k-block major: wave-load i = (k-block i / TW, tile i % TW), 1 KiB each
+    // for ALL k; its stream of 1-KiB wave-loads is k-block major
+    // in groups of TG tiles (accumulators live at a time): wave-load i = (group i / (TG*KB), k-block, tile in group)
     static constexpr int TW = N / 16 / (DEN_THREADS / 64), KB = K / 32;
-    static_assert(!WT::MFMA || (TW * 16 * (DEN_THREADS / 64) == N && KB * 32 == K && TW * KB == TOT * DEN_CH), "unsupported MFMA GEMV shape");
+    static constexpr int TG = (TW % 4 == 0) ? 4 : ((TW % 3 == 0) ? 3 : ((TW % 2 == 0) ? 2 : 1));
+    static constexpr int GL = TG * KB;                                              // wave-loads per group
+    static_assert(!WT::MFMA || (TW * 16 * (DEN_THREADS / 64) == N && KB * 32 == K && TW * KB == TOT * DEN_CH && GL % DEN_CH == 0),
+                  "unsupported MFMA GEMV shape");
     __device__ static __forceinline__ void item(int tid, int it, int& ks, int& n0) {
         const int idx = tid + it * DEN_THREADS;
         ks = idx / G0; n0 = idx - ks * G0;
@@ -228,9 +232,12 @@ __device__ __forceinline__ void consume(const u32x4 (&b)[DEN_CH], const float* _
 }
 
 // Where a GEMV reads its input: fp32 path = the fp32 vector(s) in LDS (broadcast reads); matrix-core path = this
-// lane's row of the 16-bit input fragments, [k-block][k-group 4][row 4*MS][8 halves], rows 4s+p = part p of
-// sample s (lanes whose row is unused point at 16 zero bytes, stride 0).
-struct XIn { const float* xf; const char* frag; int fstride; };
+// lane's row of the 16-bit input fragments, [k-block][k-group 4][row 4*MS][8 halves], row 4s+p = part p of
+// sample s.  Lanes whose operand row (lane % 16) has no part simply re-read another row: operand rows are
+// independent in a matrix product, so they only fill accumulator rows nobody reads.  The k-block stride is a
+// compile-time constant (an immediate offset of the LDS read).
+struct XIn { const float* xf; const char* fbase; int foff; };   // fragment row of this lane = fbase (LDS) + foff bytes
+#define XFRAG_STRIDE(MS) (4 * 4 * (MS) * 16)
 
 // Accumulators of one GEMV.  fp32 path: [sample][output half][2] packed pairs.  Matrix-core path: one 16x16
 // tile per owned output tile; lanes 16s .. 16s+15 end up with the PARTS partial products of sample s for the
@@ -238,11 +245,11 @@ struct XIn { const float* xf; const char* frag; int fstride; };
 template <typename WT, int MS, int G>
 struct Acc {
     f2 v[WT::MFMA ? 1 : MS][2][2];
-    f32x4 m[WT::MFMA ? GS<WT, G>::TW : 1];
+    f32x4 m[WT::MFMA ? GS<WT, G>::TG : 1];
     __device__ __forceinline__ void zero() {
         if constexpr (WT::MFMA) {
 #pragma unroll
-            for (int t = 0; t < GS<WT, G>::TW; ++t) m[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < GS<WT, G>::TG; ++t) m[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
 #pragma unroll
             for (int s = 0; s < MS; ++s)
@@ -256,7 +263,7 @@ struct Acc {
     __device__ __forceinline__ void pin() {
         if constexpr (WT::MFMA) {
 #pragma unroll
-            for (int t = 0; t < GS<WT, G>::TW; ++t) asm volatile("" : "+v"(m[t]) :: "memory");
+            for (int t = 0; t < GS<WT, G>::TG; ++t) asm volatile("" : "+v"(m[t]) :: "memory");
         } else {
 #pragma unroll
             for (int s = 0; s < MS; ++s)
@@ -286,26 +293,26 @@ __device__ __forceinline__ void gemv_chunk(Ring& ring, int tid, __amdgpu_buffer_
         uint4 a4 = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
         for (int j = 0; j < DEN_CH; ++j) {
-            constexpr int dummy = 0; (void)dummy;
-            const int i = C * DEN_CH + j, kb = i / S::TW, t = i % S::TW;
-            if (j == 0 || t == 0) a4 = *reinterpret_cast<const uint4*>(x.frag + kb * x.fstride);
+            const int i = C * DEN_CH + j, grp = i / S::GL, ii = i % S::GL, kb = ii / S::TG, t = ii % S::TG;
+            if (ii == 0) acc.zero();
+            if (j == 0 || t == 0) a4 = *reinterpret_cast<const uint4*>(x.fbase + x.foff + kb * XFRAG_STRIDE(MS));
 #ifndef DEN_DBG_NOFMA
             if constexpr (WT::HALF) acc.m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a4), __builtin_bit_cast(h16x8, ring.r[SLOT][j]), acc.m[t], 0, 0, 0);
             else acc.m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a4), __builtin_bit_cast(bf16x8, ring.r[SLOT][j]), acc.m[t], 0, 0, 0);
 #else
             acc.m[t].x += __uint_as_float(ring.r[SLOT][j].x ^ ring.r[SLOT][j].y ^ ring.r[SLOT][j].z ^ ring.r[SLOT][j].w ^ a4.x);
 #endif
-        }
-        if constexpr (C == S::TOT - 1) {
-            // lanes 16s .. 16s+15: outputs (wave*TW + t)*16 + lane%16 of sample s = sum of the input parts
-            const int lane = tid & 63, sl = lane >> 4;
-            if (sl < MS) {
+            if (ii == S::GL - 1) {
+                // lanes 16s .. 16s+15: outputs (wave*TW + grp*TG + t)*16 + lane%16 of sample s = sum of the input parts
+                const int lane = tid & 63, sl = lane >> 4;
+                if (sl < MS) {
 #pragma unroll
-                for (int t = 0; t < S::TW; ++t) {
-                    float val;
-                    if constexpr (WT::HALF) val = fmaf(acc.m[t].y, 1.f / DEN_F16_LO_SCALE, acc.m[t].x);
-                    else val = acc.m[t].x + (acc.m[t].y + acc.m[t].z);
-                    part[sl * S::N + ((tid >> 6) * S::TW + t) * 16 + (lane & 15)] = val;
+                    for (int t2 = 0; t2 < S::TG; ++t2) {
+                        float val;
+                        if constexpr (WT::HALF) val = fmaf(acc.m[t2].y, 1.f / DEN_F16_LO_SCALE, acc.m[t2].x);
+                        else val = acc.m[t2].x + (acc.m[t2].y + acc.m[t2].z);
+                        part[sl * S::N + ((tid >> 6) * S::TW + grp * S::TG + t2) * 16 + (lane & 15)] = val;
+                    }
                 }
             }
         }
@@ -342,12 +349,14 @@ __device__ __forceinline__ void gemv_chunks(Ring& ring, int tid, __amdgpu_buffer
 // barrier B.  On entry and exit DEN_R chunks are in flight ahead of the consumer.
 template <typename WT, int V, int MS, int G, bool LAST>
 __device__ __forceinline__ void gemv_stream(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip,
-                                            const XIn& x, float* __restrict__ part) {
+                                            const XIn& xin_, float* __restrict__ part) {
     typedef Prog<WT, V> P;
     constexpr int REL0 = (G == G_SKIP) ? -P::TS : P::start(P::pos(G));
     constexpr int NC = GS<WT, G>::TOT + (LAST ? P::PAD : 0);
     constexpr int BURST = NC < 2 ? NC : 2;
     asm volatile("" : "+v"(tid));   // addresses are recomputed per GEMV, not kept live across the layer body
+    XIn x = xin_;
+    asm volatile("" : "+v"(x.foff));   // (an int, so the LDS address space of fbase stays visible to the compiler)
     Acc<WT, MS, G> acc;
     acc.zero();
     gemv_chunks<WT, V, MS, G, REL0, NC, BURST>(ring, tid, rsrc, mo, nskip, x, part, acc, std::make_integer_sequence<int, NC>{});
@@ -445,12 +454,13 @@ __device__ __forceinline__ void put_x(float* __restrict__ xb, int s, int k0, int
 // ------------------------------------------------------------------ the persistent sampling kernel
 #define VP_LAYER (256 + 768 + 256 * 3 + FF_SA + 256 * 9 + FF_D + 256 * 4)   // floats of vector params per layer
 #define STG_TT 1536  // time-token K|V (512) + AdaLN rows (1024) of one layer
-// floats of the GEMV input buffer: fp32 vectors, or the 16-bit fragments (8 KiB per sample) + one zero vector
-#define XB_FLOATS(mfma, MS) ((mfma) ? (MS) * 2048 + 4 : (MS) * XB_LD)
+// floats of the GEMV input buffer: fp32 vectors, or the 16-bit fragments (8 KiB per sample)
+#define XB_FLOATS(mfma, MS) ((mfma) ? (MS) * 2048 : (MS) * XB_LD)
 
 struct DenKArgs {
     const void* wg; int wg_bytes; const float* vp;
-    const DenLayout* lay;      // device copy of the layout (scalar loads on demand; keeps SGPR pressure low)
+    DenLayout lay;             // by value: offsets are read with scalar loads from the kernel-argument segment (through a
+                               // device pointer the compiler issues vector loads, whose waits drain the weight ring)
     int nhead;
     SeemeSampleArgs s;
 };
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     // wave-uniform buffer descriptor of the packed weight image (raw buffer loads: VGPR offset + SGPR offset)
     const __amdgpu_buffer_rsrc_t wg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ka.wg), 0, ka.wg_bytes, 0x00020000);
     const float* __restrict__ vp = ka.vp;
-    const DenLayout* __restrict__ lay = ka.lay;
+    const DenLayout* __restrict__ lay = &ka.lay;
     const SeemeSampleArgs& A = ka.s;
     const int tid0 = threadIdx.x;
     const int b = blockIdx.x, N = A.N, H = ka.nhead;
@@ -518,23 +528,24 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     const int ca_R = A.trow_per_sample ? 1 : A.steps;
 
     float* CONSTV = smem;                        // [768]            query_pos.pe[0], encoder.norm.{weight,bias}
-    float* STG = CONSTV + 768;                   // [2][stg_sz]      per-layer operands, double-buffered
+    float* KEEP = CONSTV + 768;                  // [MS][3][256]     per sample: latent, skip inputs of layers 0 / 1 (epilogue wave's own)
+    float* STG = KEEP + MS * 768;                   // [2][stg_sz]      per-layer operands, double-buffered
     float* XB = STG + 2 * stg_sz;                // fp32 path: [MS][XB_LD] GEMV input; matrix-core path: 16-bit input
-                                                 // fragments [32 k-blocks][4][4*MS rows][8] + 16 zero bytes
+                                                 // fragments [32 k-blocks][4][4*MS rows][8]
     float* PART = XB + XB_FLOATS(WT::MFMA, MS);  // fp32 path: [4*MS*768] partial sums (k-slice major); matrix-core: [MS][1024]
     XIn xin;
     xin.xf = XB;
     {
-        const int row = lane & 15, kg = lane >> 4;
-        const bool used = WT::MFMA && (row >> 2) < MS && (row & 3) < WT::PARTS;
-        xin.frag = reinterpret_cast<const char*>(XB) + (used ? (kg * 4 * MS + row) * 16 : MS * 8192);
-        xin.fstride = used ? 4 * 4 * MS * 16 : 0;
+        const int row = (lane & 15) % (4 * MS), kg = lane >> 4;
+        xin.fbase = reinterpret_cast<const char*>(XB);
+        xin.foff = (kg * 4 * MS + row) * 16;
     }
 
     const float sa_scale = 1.f / sqrtf((float)(256 / H));
     if (epi) __builtin_amdgcn_s_setprio(3);      // the chain of dependent epilogues is the critical path
-    float4 lat = ld4(A.latents + (size_t)b * 256 + 4 * lane);
-    float4 xr = lat, sk0 = lat, sk1 = lat;
+    float* const keep = KEEP + es * 768 + 4 * lane;   // [0] latent, [256] layer-0 output, [512] layer-1 output
+    float4 xr = ld4(A.latents + (size_t)b * 256 + 4 * lane);
+    if (epi) st4(keep, xr);
 
     // ---- prologue: constants, layer 0 operands, first input vector, first DEN_R chunks
     int row = A.trow_per_sample ? A.trow[b] : A.trow[0];
@@ -545,7 +556,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
         if (WT::MFMA) for (int i = tid0; i < XB_FLOATS(true, MS) / 4; i += DEN_THREADS) st4(XB + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
         wait_vmcnt0();
         __syncthreads();
-        if (epi) { xr = f4_add(lat, ld4(CONSTV + 4 * lane)); sk0 = xr; sk1 = xr; put_x<WT, MS>(XB, es, 0, lane, xr); }   // mld_denoiser.py:210
+        if (epi) { xr = f4_add(xr, ld4(CONSTV + 4 * lane)); put_x<WT, MS>(XB, es, 0, lane, xr); }   // mld_denoiser.py:210
     }
     Ring ring;
     {
@@ -740,10 +751,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             if (l + 1 < SEEME_DEN_NL) {
                 if (epi) {
                     xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_fo_b + 4 * lane)));
-                    if (l == 0) sk0 = xr;
-                    if (l == 1) sk1 = xr;
+                    if (l < 2) st4(keep + 256 + 256 * l, xr);                                   // xs.append(x) (cross_attention.py:70-72)
                     put_x<WT, MS>(XB, es, 0, lane, xr);
-                    if (nskip) put_x<WT, MS>(XB, es, 256, lane, ln == 3 ? sk1 : sk0);
+                    if (nskip) put_x<WT, MS>(XB, es, 256, lane, ld4(keep + (ln == 3 ? 512 : 256)));   // xs.pop(): layer 3 <- layer 1, layer 4 <- layer 0
                 }
                 __syncthreads();
             } else {
@@ -763,13 +773,14 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                     }
                 }
                 if (A.sched == SEEME_SCHED_NONE) {   // steps == 1 by contract: the output is the model output
-                    lat = e;
+                    if (epi) st4(keep, e);
                 } else if (epi) {
                     // ---- scheduler.step (mld.py:495-497; scalars prepared by seeme_amd/schedulers.py)
                     const float* __restrict__ c = A.coef + (size_t)step * 8;
                     const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], clip = c[6], ptype = c[7];
                     float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (A.noise != nullptr) nz = ld4(A.noise + ((size_t)step * A.B + b) * 256 + 4 * lane);
+                    const float4 lat = ld4(keep);
                     const float xs[4] = {lat.x, lat.y, lat.z, lat.w}, es4[4] = {e.x, e.y, e.z, e.w}, ns[4] = {nz.x, nz.y, nz.z, nz.w};
                     float o[4];
 #pragma unroll
@@ -780,9 +791,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                         if (clip != 0.f) x0 = fminf(fmaxf(x0, -1.f), 1.f);
                         o[i] = c2 * x0 + c3 * ep + c5 * xs[i] + c4 * ns[i];
                     }
-                    lat = make_float4(o[0], o[1], o[2], o[3]);
-                    xr = f4_add(lat, ld4(CONSTV + 4 * lane));                        // next step: sample + query_pos
-                    sk0 = xr; sk1 = xr;
+                    const float4 nl = make_float4(o[0], o[1], o[2], o[3]);
+                    st4(keep, nl);
+                    xr = f4_add(nl, ld4(CONSTV + 4 * lane));                         // next step: sample + query_pos
                     put_x<WT, MS>(XB, es, 0, lane, xr);
                 }
                 __syncthreads();
@@ -791,14 +802,14 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
         }
         row = row_next;
     }
-    if (tid0 < 64) st4(A.out + (size_t)b * 256 + 4 * tid0, lat);
+    if (tid0 < 64) st4(A.out + (size_t)b * 256 + 4 * tid0, ld4(KEEP + 4 * tid0));   // (sample 0 / the guided latent)
     // the last requested chunks are never consumed: keep them from being optimised into dangling loads
 #pragma unroll
     for (int s = 0; s < DEN_R; ++s) asm volatile("" ::"v"(ring.r[s][0].x));
 }
 
 static size_t den_lds_bytes(int MS, int N, bool mfma) {
-    return (size_t)(768 + 2 * (VP_LAYER + STG_TT + MS * N * 1024 + (N > 1 ? 0 : MS * 256)) + XB_FLOATS(mfma, MS) + (mfma ? MS * 1024 : 4 * MS * 768)) * sizeof(float);
+    return (size_t)(768 + MS * 768 + 2 * (VP_LAYER + STG_TT + MS * N * 1024 + (N > 1 ? 0 : MS * 256)) + XB_FLOATS(mfma, MS) + (mfma ? MS * 1024 : 4 * MS * 768)) * sizeof(float);
 }
 
 template <typename WT, int MS, int V>
@@ -829,11 +840,8 @@ extern "C" int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeS
     if (a->sched == SEEME_SCHED_NONE && a->steps != 1) return seeme_fail("denoiser_sample: SCHED_NONE needs steps == 1");
     if (a->steps < 1) return seeme_fail("denoiser_sample: steps must be >= 1");
     DenKArgs ka;
-    ka.wg = w->wg; ka.vp = w->vp; ka.lay = reinterpret_cast<const DenLayout*>(w->layout);
-    {
-        const DenLayout hl = seeme_make_den_layout(FF_SA, FF_D);
-        ka.wg_bytes = (int)(hl.wg_total * (w->wdtype == 0 ? 4 : 2));
-    }
+    ka.wg = w->wg; ka.vp = w->vp; ka.lay = seeme_make_den_layout(FF_SA, FF_D);
+    ka.wg_bytes = (int)(ka.lay.wg_total * (w->wdtype == 0 ? 4 : 2));
     ka.nhead = w->nhead; ka.s = *a;
     hipStream_t st = (hipStream_t)stream;
     const bool fold = w->sa_fold != 0;

@@ -6,7 +6,7 @@
 //
 // wg offsets are in ELEMENTS of the weight dtype; a PyTorch [N,K] fp32 matrix is stored
 // in "GEMV layout" [K/KV][N][KV], KV = 4; a bf16 / fp16 matrix as the per-wave matrix-core operand
-// stream [wave 8][k-block K/32][tile N/128][lane 64][8] (seeme_amd/mld_denoiser.py put_w).  vp offsets are in floats.
+// stream [wave 8][tile group][k-block K/32][tile in group][lane 64][8] (seeme_amd/mld_denoiser.py put_w).  vp offsets are in floats.
 #pragma once
 #include <stdint.h>
 

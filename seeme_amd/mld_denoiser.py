@@ -181,11 +181,12 @@ class MldDenoiser(nn.Module):
         def put_w(off, W):
             N, K = W.shape
             if bf16:
-                # matrix-core stream (den_kernels.hip, GS::TW / KB): wave w owns output tiles w*TW .. w*TW+TW-1 (16
-                # outputs each) for all k; wave-load i = (k-block i // TW, tile i % TW); lane = 16*(k-group) + output
-                # row holds 8 consecutive k -- the v_mfma_f32_16x16x32 operand layout
+                # matrix-core stream (den_kernels.hip, GS::TW / TG / KB): wave w owns output tiles w*TW .. w*TW+TW-1 (16
+                # outputs each) for all k, in groups of TG tiles; within a group k-block major, then tile; lane =
+                # 16*(k-group) + output row holds 8 consecutive k -- the v_mfma_f32_16x16x32 operand layout
                 TW, KB = N // 128, K // 32
-                g = W.detach().reshape(8, TW, 16, KB, 4, 8).permute(0, 3, 1, 4, 2, 5).reshape(-1)
+                TG = 4 if TW % 4 == 0 else (3 if TW % 3 == 0 else (2 if TW % 2 == 0 else 1))
+                g = W.detach().reshape(8, TW // TG, TG, 16, KB, 4, 8).permute(0, 1, 4, 2, 5, 3, 6).reshape(-1)
             else:
                 # vector-ALU stream: [K/KV][N][KV] 16-byte vectors
                 g = W.detach().reshape(N, K // KV, KV).permute(1, 0, 2).reshape(-1)
