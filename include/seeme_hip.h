@@ -150,8 +150,8 @@ typedef struct {
     const float* ln_ones; const float* ln_zeros;                                /* [256] each */
     int sa_fold;                                                                /* 1: out_proj folded into V (nhead == 1) */
     /* ca_block.proj_out of each layer (StylizationBlock, mdiff_transformer.py:152-163), for seeme_denoiser_ca_tables */
-    const float* ca_pn_w[SEEME_NLAYERS]; const float* ca_pn_b[SEEME_NLAYERS];   /* proj_out.norm [256] */
-    const float* ca_po_w[SEEME_NLAYERS]; const float* ca_po_b[SEEME_NLAYERS];   /* proj_out.out_layers.2 [256,256], [256] */
+    const float* ca_pn_w; const float* ca_pn_b;   /* proj_out.norm of the 5 layers, [5,256] each */
+    const float* ca_po_w; const float* ca_po_b;   /* proj_out.out_layers.2 of the 5 layers, [5,256,256] and [5,256] */
 } SeemeDenoiserWeights;
 
 /* per-row time tables: floats per row = 5*512 (sa K|V of the time token) + 5*1024 (AdaLN scale|shift, ca|ffn) */
@@ -177,7 +177,7 @@ int seeme_denoiser_cond_tables(const SeemeDenoiserWeights* w, const float* cond,
  *   catab[bc][r][l] = proj_out.out_layers( SiLU( LN(value_l(cond_bc)) * (1 + scale_{row,l}) + shift_{row,l} ) )
  * with row = trow[r] (trow_per_sample 0, R = n_rows rows per sample) or trow[bc % n_b] (trow_per_sample 1, R = 1,
  * n_b = number of trow entries).  ctab [Bc,1,SEEME_CROW]; catab [Bc,R,5,256].
- * workspace >= Bc*R*256 floats. */
+ * workspace >= 5*Bc*R*256 floats. */
 int seeme_denoiser_ca_tables(const SeemeDenoiserWeights* w, const float* ctab, const float* ttab, const int32_t* trow,
                              int trow_per_sample, int n_trow, int Bc, float* catab,
                              void* workspace, size_t ws_bytes, void* stream);

@@ -77,7 +77,7 @@ class DenoiserWeights(C.Structure):
                 ("ca_kv_w", fp * NLAYERS), ("ca_kv_b", fp * NLAYERS),
                 ("ca_tn_w", fp * NLAYERS), ("ca_tn_b", fp * NLAYERS),
                 ("ca_fold_w", fp), ("ca_fold_b", fp), ("ln_ones", fp), ("ln_zeros", fp), ("sa_fold", C.c_int),
-                ("ca_pn_w", fp * NLAYERS), ("ca_pn_b", fp * NLAYERS), ("ca_po_w", fp * NLAYERS), ("ca_po_b", fp * NLAYERS)]
+                ("ca_pn_w", fp), ("ca_pn_b", fp), ("ca_po_w", fp), ("ca_po_b", fp)]
 
 
 class SampleArgs(C.Structure):

@@ -27,6 +27,9 @@ struct LinearKArgs {
     int res_mode;      // 0: residual row = output row; 1: (m % seq_in) + res_off (positional embedding add);
                        // 2: m / seq_in (one row per sequence: broadcast vector)
     int res_off;
+    // optional batch of independent problems over blockIdx.z (element strides per z; nz = 0 or 1: single problem)
+    int nz;
+    long zs_a, zs_w, zs_b, zs_y, zs_ln;
 };
 int seeme_launch_linear(const LinearKArgs& ka, hipStream_t st);
 int seeme_linear_simple(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias,

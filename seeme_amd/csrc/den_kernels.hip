@@ -905,23 +905,19 @@ extern "C" int seeme_denoiser_cond_tables(const SeemeDenoiserWeights* w, const f
 }
 
 // ------------------------------------------------------------------ ca_block table for ONE condition token
-// H[(bc*R + r)][256] = SiLU( LN(value_l(cond_bc); proj_out.norm) * (1 + scale) + shift ), one wave per row
+// H[l][(bc*R + r)][256] = SiLU( LN(value_l(cond_bc); proj_out.norm) * (1 + scale) + shift ), one wave per row
 __global__ __launch_bounds__(256) void k_ca_rows(const float* __restrict__ ctab, const float* __restrict__ ttab,
-                                                 const int32_t* __restrict__ trow, int per_sample, int n_trow, int R, int rows, int l,
+                                                 const int32_t* __restrict__ trow, int per_sample, int n_trow, int R, int rows,
                                                  const float* __restrict__ nw, const float* __restrict__ nb, float* __restrict__ H) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, l = blockIdx.y;
     const int r0 = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r0 >= rows) return;
     const int bc = r0 / R, r = r0 - bc * R;
     const int row = per_sample ? trow[bc % n_trow] : trow[r];
     const float4 v = ld4(ctab + (size_t)bc * SEEME_CROW + 2560 + l * 512 + 256 + 4 * lane);
-    const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
-    const float4 c = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
-    const float rs = 1.f / sqrtf(wave_sum(f4_dot(c, c)) * (1.f / 256.f) + 1e-5f);
-    const float4 wv = ld4(nw + 4 * lane), bv = ld4(nb + 4 * lane);
-    const float4 hn = make_float4(c.x * rs * wv.x + bv.x, c.y * rs * wv.y + bv.y, c.z * rs * wv.z + bv.z, c.w * rs * wv.w + bv.w);
+    const float4 hn = wave_ln(v, nw + l * 256, nb + l * 256, lane);
     const float* tt = ttab + (size_t)row * SEEME_TROW + 2560 + l * 1024;
-    st4(H + (size_t)r0 * 256 + 4 * lane, f4_silu(f4_adaln(hn, ld4(tt + 4 * lane), ld4(tt + 256 + 4 * lane))));
+    st4(H + ((size_t)l * rows + r0) * 256 + 4 * lane, f4_silu(f4_adaln(hn, ld4(tt + 4 * lane), ld4(tt + 256 + 4 * lane))));
 }
 
 extern "C" int seeme_denoiser_ca_tables(const SeemeDenoiserWeights* w, const float* ctab, const float* ttab, const int32_t* trow,
@@ -931,17 +927,17 @@ extern "C" int seeme_denoiser_ca_tables(const SeemeDenoiserWeights* w, const flo
     if (Bc <= 0 || n_trow <= 0) return seeme_fail("ca_tables: empty batch / row list");
     const int R = trow_per_sample ? 1 : n_trow;
     const int rows = Bc * R;
-    if (ws_bytes < (size_t)rows * 256 * sizeof(float)) return seeme_fail("ca_tables: workspace too small");
+    if (ws_bytes < (size_t)SEEME_DEN_NL * rows * 256 * sizeof(float)) return seeme_fail("ca_tables: workspace too small");
+    if (w->ca_pn_w == nullptr || w->ca_po_w == nullptr) return seeme_fail("ca_tables: proj_out weights missing");
     float* H = (float*)workspace;
-    for (int l = 0; l < SEEME_DEN_NL; ++l) {
-        if (w->ca_pn_w[l] == nullptr || w->ca_po_w[l] == nullptr) return seeme_fail("ca_tables: proj_out weights missing");
-        hipLaunchKernelGGL(k_ca_rows, dim3((rows + 3) / 4), dim3(256), 0, st, ctab, ttab, trow, trow_per_sample, n_trow, R, rows, l,
-                           w->ca_pn_w[l], w->ca_pn_b[l], H);
-        int rc = seeme_check_launch("k_ca_rows");
-        if (rc) return rc;
-        // proj_out.out_layers: Linear(256,256) -> catab[:, :, l, :]
-        if ((rc = seeme_linear_simple(st, H, 256, w->ca_po_w[l], 256, w->ca_po_b[l], catab + l * 256, SEEME_DEN_NL * 256, rows, 256, 256,
-                                      0, 0, nullptr, nullptr))) return rc;
-    }
-    return 0;
+    hipLaunchKernelGGL(k_ca_rows, dim3((rows + 3) / 4, SEEME_DEN_NL), dim3(256), 0, st, ctab, ttab, trow, trow_per_sample, n_trow, R, rows,
+                       w->ca_pn_w, w->ca_pn_b, H);
+    int rc = seeme_check_launch("k_ca_rows");
+    if (rc) return rc;
+    // proj_out.out_layers of the five layers as one batched launch: Linear(256,256) -> catab[:, :, l, :]
+    LinearKArgs ka{};
+    ka.a.A = H; ka.a.lda = 256; ka.a.K1 = 256; ka.a.W = w->ca_po_w; ka.a.ldw = 256; ka.a.bias = w->ca_po_b;
+    ka.a.Y = catab; ka.a.ldy = SEEME_DEN_NL * 256; ka.a.M = rows; ka.a.N = 256; ka.a.K = 256; ka.a.eps = 1e-5f;
+    ka.nz = SEEME_DEN_NL; ka.zs_a = (long)rows * 256; ka.zs_w = 256 * 256; ka.zs_b = 256; ka.zs_y = 256;
+    return seeme_launch_linear(ka, st);
 }

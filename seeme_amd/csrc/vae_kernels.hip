@@ -13,7 +13,13 @@
 
 __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const SeemeLinearArgs& a = ka.a;
+    SeemeLinearArgs a = ka.a;
+    if (ka.nz > 1) {   // batch of independent problems over blockIdx.z
+        const long z = blockIdx.z;
+        a.A += z * ka.zs_a; a.W += z * ka.zs_w; a.Y += z * ka.zs_y;
+        if (a.bias) a.bias += z * ka.zs_b;
+        if (a.pre_ln_w) { a.pre_ln_w += z * ka.zs_ln; a.pre_ln_b += z * ka.zs_ln; }
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Kp = (a.K + 15) & ~15;
     const int lda_s = Kp + LDS_PAD;
@@ -124,7 +130,7 @@ int seeme_launch_linear(const LinearKArgs& ka, hipStream_t st) {
     if ((a.ldw & 3) != 0) return seeme_fail("seeme_linear: ldw must be a multiple of 4");
     if (Kp > 1024) return seeme_fail("seeme_linear: K > 1024 not supported");
     const size_t lds = (size_t)(TILE_M * (Kp + LDS_PAD) + TILE_M * (CH_N + LDS_PAD)) * sizeof(float);
-    dim3 grid((a.M + TILE_M - 1) / TILE_M, (a.N + CH_N - 1) / CH_N);
+    dim3 grid((a.M + TILE_M - 1) / TILE_M, (a.N + CH_N - 1) / CH_N, ka.nz > 1 ? ka.nz : 1);
     SEEME_HIP(hipFuncSetAttribute((const void*)k_linear, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_linear, grid, dim3(256), lds, st, ka);
     return seeme_check_launch("k_linear");

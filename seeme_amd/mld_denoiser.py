@@ -258,12 +258,15 @@ class MldDenoiser(nn.Module):
         for l, b in enumerate(blocks):
             w.ca_kv_w[l], w.ca_kv_b[l] = ca_w[l].data_ptr(), ca_b[l].data_ptr()
             w.ca_tn_w[l], w.ca_tn_b[l] = L.ptr(b.ca_block.text_norm.weight), L.ptr(b.ca_block.text_norm.bias)
-            po = b.ca_block.proj_out
-            w.ca_pn_w[l], w.ca_pn_b[l] = L.ptr(po.norm.weight), L.ptr(po.norm.bias)
-            w.ca_po_w[l], w.ca_po_b[l] = L.ptr(po.out_layers[2].weight), L.ptr(po.out_layers[2].bias)
+        with torch.no_grad():   # ca_block.proj_out of the five layers, stacked for the batched table builder
+            pn_w = torch.stack([b.ca_block.proj_out.norm.weight for b in blocks]).contiguous()
+            pn_b = torch.stack([b.ca_block.proj_out.norm.bias for b in blocks]).contiguous()
+            po_w = torch.stack([b.ca_block.proj_out.out_layers[2].weight for b in blocks]).contiguous()
+            po_b = torch.stack([b.ca_block.proj_out.out_layers[2].bias for b in blocks]).contiguous()
+        w.ca_pn_w, w.ca_pn_b, w.ca_po_w, w.ca_po_b = pn_w.data_ptr(), pn_b.data_ptr(), po_w.data_ptr(), po_b.data_ptr()
         w.sa_fold = int(fold)
         w.ca_fold_w, w.ca_fold_b, w.ln_ones, w.ln_zeros = cf_w.data_ptr(), cf_b.data_ptr(), ones.data_ptr(), zeros.data_ptr()
-        self._wcache = (fpnt, w, (wg, vp, kv_w, kv_b, st_w, st_b, ca_w, ca_b, lay_dev, cf_w, cf_b, ones, zeros))
+        self._wcache = (fpnt, w, (wg, vp, kv_w, kv_b, st_w, st_b, ca_w, ca_b, lay_dev, cf_w, cf_b, ones, zeros, pn_w, pn_b, po_w, po_b))
         self._table_cache = {}
         return w
 
@@ -304,7 +307,7 @@ class MldDenoiser(nn.Module):
         Bc = ctab.shape[0]
         R = 1 if per_sample else trow.numel()
         catab = torch.empty(Bc, R, 5, self.latent_dim, device=ctab.device, dtype=torch.float32)
-        ws = torch.empty(Bc * R * 256, device=ctab.device, dtype=torch.float32)
+        ws = torch.empty(5 * Bc * R * 256, device=ctab.device, dtype=torch.float32)
         w = self._weights()
         L.check(L.lib().seeme_denoiser_ca_tables(C.byref(w), ctab.data_ptr(), ttab.data_ptr(), trow.data_ptr(), int(per_sample),
                                                   trow.numel(), Bc, catab.data_ptr(), ws.data_ptr(), ws.numel() * 4,
@@ -365,10 +368,11 @@ class MldDenoiser(nn.Module):
                                       self.freq_shift).to(dev)
             coef = scheduler.coef_table(eta).to(dev)
             trow = torch.arange(len(scheduler.timesteps), dtype=torch.int32, device=dev)
-            cached = (tfeat, coef, trow)
+            # the time tables are a function of (weights, timestep schedule) only -- like the packed weight image
+            # they are built once per scheduler configuration (_weights() drops the cache when a parameter changes)
+            cached = (tfeat, coef, trow, self.time_tables(tfeat))
             self._table_cache = {key: cached}
-        tfeat, coef, trow = cached
-        ttab = self.time_tables(tfeat)                     # batch-invariant: once per call
+        tfeat, coef, trow, ttab = cached
         ctab = self.cond_tables(cond_bf)
         steps = len(trow)
         noise = None
