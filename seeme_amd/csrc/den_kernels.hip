@@ -115,16 +115,39 @@ struct Prog {
             default: return GS<WT, G_FO>::TOT;
         }
     }
-    static constexpr int start(int i) { int s = 0; for (int j = 0; j < i; ++j) s += tot(gid(j)); return s; }
-    static constexpr int SUM = start(NG);
-    static constexpr int T = (SUM + DEN_R - 1) / DEN_R * DEN_R;
-    static constexpr int PAD = T - SUM;
+    // chunk numbering: GEMV i starts at start(i); the PAD no-op chunks that round the program up to a multiple of
+    // the ring size sit right behind in_proj (inside a long, stream-bound stage) -- at the end of the layer they
+    // would take the re-fill slots of the short FFN stages and leave the fill path idle there
+    static constexpr int sum_real() { int s = 0; for (int j = 0; j < NG; ++j) s += tot(gid(j)); return s; }
+    static constexpr int T = (sum_real() + DEN_R - 1) / DEN_R * DEN_R;
+    static constexpr int PAD = T - sum_real();
+    static constexpr int PAD0 = tot(G_INP);                                          // first pad chunk
+    static constexpr bool is_pad(int t) { return t >= PAD0 && t < PAD0 + PAD; }
+    static constexpr int start(int i) { int s = (i >= 1 ? PAD : 0); for (int j = 0; j < i; ++j) s += tot(gid(j)); return s; }
     static constexpr int TS = tot(G_SKIP);
     static constexpr int find(int t) { int i = 0; while (i + 1 < NG && start(i + 1) <= t) ++i; return i; }
     static constexpr int pos(int g) { int i = 0; while (gid(i) != g) ++i; return i; }   // position of GEMV g in P0
+    static_assert(gid(0) == G_INP, "in_proj opens the layer program");
     static_assert(TS % DEN_R == 0 && TS >= DEN_R, "skip linear must fill whole ring turns");
     static_assert(tot(G_INP) >= DEN_R, "the first GEMV of a layer must cover the cross-layer prefetch");
 };
+
+#ifdef DEN_DBG_TIMES
+// debug build only: cycle stamps of workgroup 0 / thread 0 at every barrier of one step (scripts/den_times.py)
+__device__ unsigned long long den_dbg_times[512];
+__device__ __forceinline__ void den_dbg(int mode) {   // 0: stamp, 1: arm (reset), 2: disarm, 3: dump
+    __shared__ unsigned long long buf[512];
+    __shared__ int cnt, armed;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (mode == 1) { cnt = 0; armed = 1; }
+    else if (mode == 2) { armed = 0; }
+    else if (mode == 0) { if (armed && cnt < 511) { buf[cnt] = __builtin_readcyclecounter(); cnt = cnt + 1; } }
+    else { for (int i = 0; i < cnt; ++i) den_dbg_times[i + 1] = buf[i]; den_dbg_times[0] = (unsigned long long)cnt; }
+}
+#define DEN_DBG(m) den_dbg(m)
+#else
+#define DEN_DBG(m) do {} while (0)
+#endif
 
 // ---- issue: chunk C of matrix G (base = byte offset of the matrix in the image) -> ring slot
 template <typename WT, int G, int C>
@@ -166,7 +189,7 @@ __device__ __forceinline__ MatOffs load_mat_offs(const DenLayerOff* __restrict__
 template <typename WT, int V, int T>
 __device__ __forceinline__ void issue_p0(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo) {
     typedef Prog<WT, V> P;
-    static_assert(T >= 0 && T < P::SUM, "chunk outside the layer program");
+    static_assert(T >= 0 && T < P::T && !P::is_pad(T), "chunk outside the layer program");
     constexpr int i = P::find(T), g = P::gid(i), c = T - P::start(i);
     issue_mat<WT, g, c>(ring.r[T % DEN_R], tid, rsrc, mo.m[g]);
 }
@@ -175,14 +198,14 @@ __device__ __forceinline__ void issue_p0(Ring& ring, int tid, __amdgpu_buffer_rs
 template <typename WT, int V, int T>
 __device__ __forceinline__ void issue_rel(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip) {
     typedef Prog<WT, V> P;
-    if constexpr (T < P::SUM) {
-        issue_p0<WT, V, T>(ring, tid, rsrc, mo);
-    } else if constexpr (T >= P::T) {
+    if constexpr (T < P::T) {
+        if constexpr (!P::is_pad(T)) issue_p0<WT, V, T>(ring, tid, rsrc, mo);   // (padding chunk: nothing to load)
+    } else {
         constexpr int j = T - P::T;
         static_assert(j < DEN_R && j < GS<WT, G_INP>::TOT && j < P::TS, "prefetch reaches too far into the next layer");
         if (nskip) issue_mat<WT, G_SKIP, j>(ring.r[j % DEN_R], tid, rsrc, mo.next);
         else issue_mat<WT, G_INP, j>(ring.r[j % DEN_R], tid, rsrc, mo.next);
-    }   // else: padding chunk, nothing to load
+    }
 }
 
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
@@ -349,10 +372,11 @@ __device__ __forceinline__ void gemv_chunks(Ring& ring, int tid, __amdgpu_buffer
 // barrier B.  On entry and exit DEN_R chunks are in flight ahead of the consumer.
 template <typename WT, int V, int MS, int G, bool LAST>
 __device__ __forceinline__ void gemv_stream(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip,
-                                            const XIn& xin_, float* __restrict__ part) {
+                                            const XIn& xin_, float* __restrict__ part, bool epi) {
     typedef Prog<WT, V> P;
     constexpr int REL0 = (G == G_SKIP) ? -P::TS : P::start(P::pos(G));
-    constexpr int NC = GS<WT, G>::TOT + (LAST ? P::PAD : 0);
+    constexpr int NC = GS<WT, G>::TOT + (G == G_INP ? P::PAD : 0);   // in_proj also "consumes" the padding chunks
+    (void)LAST;
     constexpr int BURST = NC < 2 ? NC : 2;
     asm volatile("" : "+v"(tid));   // addresses are recomputed per GEMV, not kept live across the layer body
     XIn x = xin_;
@@ -361,9 +385,29 @@ __device__ __forceinline__ void gemv_stream(Ring& ring, int tid, __amdgpu_buffer
     acc.zero();
     gemv_chunks<WT, V, MS, G, REL0, NC, BURST>(ring, tid, rsrc, mo, nskip, x, part, acc, std::make_integer_sequence<int, NC>{});
     __syncthreads();                                                  // barrier A: partial sums visible
+    DEN_DBG(0);
+#ifdef DEN_SLEEP
+    if (!epi) __builtin_amdgcn_s_sleep(DEN_SLEEP);                    // let the epilogue wave's re-fills enter the fill queue first
+#endif
     refill<WT, V, G, REL0, NC - BURST>(ring, tid, rsrc, mo, nskip);
     if constexpr (BURST == 2) refill<WT, V, G, REL0, NC - 1>(ring, tid, rsrc, mo, nskip);
     acc.pin();
+}
+
+// ------------------------------------------------------------------ epilogue math
+// The chain of dependent epilogues runs on ONE wave per sample, so its instruction count is latency of the
+// whole loop.  Hardware transcendental forms (1 ulp): v_exp_f32, v_rcp_f32, v_rsq_f32; erf by Abramowitz &
+// Stegun 7.1.26 (|error| <= 1.5e-7) -- all far inside the 1e-4 parity gate.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_silu(float x) { return x * fast_rcp(1.f + fast_exp(-x)); }
+__device__ __forceinline__ float fast_gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = fast_rcp(fmaf(0.3275911f, z, 1.f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erfa = 1.f - poly * fast_exp(-z * z);                   // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.f + copysignf(erfa, x));
 }
 
 // ------------------------------------------------------------------ wave-local vector algebra
@@ -395,14 +439,11 @@ __device__ __forceinline__ float seg_reduce(float v, int seg_lanes) {
 __device__ __forceinline__ float4 wave_ln(float4 v, const float* __restrict__ w, const float* __restrict__ b, int lane) {
     const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
     const float4 c = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
-    const float rs = 1.f / sqrtf(wave_sum(f4_dot(c, c)) * (1.f / 256.f) + 1e-5f);
+    const float rs = fast_rsq(wave_sum(f4_dot(c, c)) * (1.f / 256.f) + 1e-5f);
     const float4 wv = ld4(w + 4 * lane), bv = ld4(b + 4 * lane);
     return make_float4(c.x * rs * wv.x + bv.x, c.y * rs * wv.y + bv.y, c.z * rs * wv.z + bv.z, c.w * rs * wv.w + bv.w);
 }
-__device__ __forceinline__ float4 f4_silu(float4 v) {
-    return make_float4(act_apply(v.x, SEEME_ACT_SILU), act_apply(v.y, SEEME_ACT_SILU), act_apply(v.z, SEEME_ACT_SILU),
-                       act_apply(v.w, SEEME_ACT_SILU));
-}
+__device__ __forceinline__ float4 f4_silu(float4 v) { return make_float4(fast_silu(v.x), fast_silu(v.y), fast_silu(v.z), fast_silu(v.w)); }
 __device__ __forceinline__ float4 f4_adaln(float4 h, float4 scl, float4 shf) {
     return make_float4(h.x * (1.f + scl.x) + shf.x, h.y * (1.f + scl.y) + shf.y, h.z * (1.f + scl.z) + shf.z, h.w * (1.f + scl.w) + shf.w);
 }
@@ -467,11 +508,11 @@ struct DenKArgs {
 
 // Per-layer small operands (biases / LayerNorm params, the time token's K|V and AdaLN rows, the condition
 // tokens' K|V) travel global -> LDS by LDS-DMA (no registers), one layer AHEAD of their use, into the other
-// half of a double buffer: requested at the top of layer l for layer l+1, 1 KiB per wave-instruction spread
-// over the 8 waves.  vmcnt retires in issue order, so once a wave has consumed any weight chunk it requested
+// half of a double buffer: requested during layer l (in its ffn.linear1 stage) for layer l+1, 1 KiB per
+// wave-instruction spread over the non-epilogue waves.  vmcnt retires in issue order, so once a wave has consumed any weight chunk it requested
 // later, its copies have landed; the barriers of layer l then publish them.  (hipcc does not count the asm
 // DMA: its own vmcnt(N) waits only become slightly longer, never shorter.)
-template <int MS, bool CAQ>
+template <int MS, bool CAQ, int W0>
 __device__ __forceinline__ void stage_dma(int wave, int lane, float* __restrict__ stg, const float* __restrict__ vpg,
                                           const DenLayerOff* __restrict__ L, const float* __restrict__ tt_row, int l,
                                           const SeemeSampleArgs& A, int b, int N, int ca_r, int ca_R) {
@@ -479,7 +520,7 @@ __device__ __forceinline__ void stage_dma(int wave, int lane, float* __restrict_
     const int ncond = 31 + 4 * MS * N;
     const int total = ncond + (CAQ ? 0 : MS);
 #pragma unroll 1
-    for (int c = wave; c < total; c += DEN_THREADS / 64) {
+    for (int c = wave - W0; c < total; c += DEN_THREADS / 64 - W0) {   // waves W0 .. 7 share the copies
         const float* src;
         int dst, lanes = 64;
         if (c < 25) {                       // VP_LAYER = 24.5 KiB of vector params
@@ -541,7 +582,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
         xin.foff = (kg * 4 * MS + row) * 16;
     }
 
-    const float sa_scale = 1.f / sqrtf((float)(256 / H));
+    const float sa_scale = 1.f / sqrtf((float)(256 / H));   // (once per kernel)
     if (epi) __builtin_amdgcn_s_setprio(3);      // the chain of dependent epilogues is the critical path
     float* const keep = KEEP + es * 768 + 4 * lane;   // [0] latent, [256] layer-0 output, [512] layer-1 output
     float4 xr = ld4(A.latents + (size_t)b * 256 + 4 * lane);
@@ -552,7 +593,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     {
         for (int i = tid0; i < 192; i += DEN_THREADS)
             st4(CONSTV + 4 * i, i < 64 ? ld4(vp + lay->pe0 + 4 * i) : (i < 128 ? ld4(vp + lay->fnw + 4 * (i - 64)) : ld4(vp + lay->fnb + 4 * (i - 128))));
-        stage_dma<MS, CAQ>(wave, lane, STG, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b, N, 0, ca_R);
+        stage_dma<MS, CAQ, 0>(wave, lane, STG, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b, N, 0, ca_R);
         if (WT::MFMA) for (int i = tid0; i < XB_FLOATS(true, MS) / 4; i += DEN_THREADS) st4(XB + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
         wait_vmcnt0();
         __syncthreads();
@@ -570,6 +611,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
 
 #pragma unroll 1
     for (int step = 0; step < A.steps; ++step) {
+        if (step == 2) DEN_DBG(1);
+        if (step == 3) DEN_DBG(2);
         // table row of the NEXT step (the last layer stages layer 0 of the next step)
         const int step_next = step + 1 < A.steps ? step + 1 : step;
         const int row_next = A.trow_per_sample ? row : A.trow[step_next];
@@ -589,9 +632,6 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             const float* CTS = TTS + STG_TT;                 // [MS][N][1024] condition K|V (sa 512 | ca 512)
             const float* CT = CTS + es * N * 1024;
             const float* CA_ADD = CTS + MS * N * 1024 + es * 256;   // (one condition token) tabulated ca_block term
-            // request the next layer's operands (LDS-DMA into the other half of the double buffer)
-            stage_dma<MS, CAQ>(wave, lane, STG + (cur ^ 1) * stg_sz, vp, Ln, A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW, ln, A, b, N,
-                                A.trow_per_sample ? 0 : (ln == 0 ? step_next : step), ca_R);
             // offsets inside VP (relative to skip_b)
             const float* v_skip_b = VP;
             const float* v_in_b = VP + (L->in_b - L->skip_b);
@@ -610,16 +650,16 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             // ---- skip connection: Linear(cat[x, xs.pop()])  (cross_attention.py:77-79); input staged by the
             //      previous layer's last epilogue
             if (l >= 3) {
-                gemv_stream<WT, V, MS, G_SKIP, false>(ring, tid, wg, mo, nskip, xin, PART);
+                gemv_stream<WT, V, MS, G_SKIP, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
                 if (epi) {
                     xr = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_skip_b + 4 * lane));
                     put_x<WT, MS>(XB, es, 0, lane, xr);
                 }
-                __syncthreads();
+                __syncthreads(); DEN_DBG(0);
             }
             // ---- sa_block: post-norm encoder layer over [x, xf.., emb]; only token 0 is kept
             //      (mdiff_transformer.py:292-297); K/V of xf and emb come from the tables.
-            gemv_stream<WT, V, MS, G_INP, false>(ring, tid, wg, mo, nskip, xin, PART);
+            gemv_stream<WT, V, MS, G_INP, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
             if (epi) {
                 // in_proj output n in [0,768): q | k | v
                 const float4 q = f4_add(gemv_out<WT, MS, G_INP>(PART, es, 0, lane), ld4(v_in_b + 4 * lane));
@@ -634,10 +674,10 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                 // the time token is the LAST of the sequence (mdiff_transformer.py:295)
                 const float st = seg_reduce<false>(f4_dot(q, ld4(TTS + 4 * lane)), seg) * sa_scale;
                 mx = fmaxf(mx, st);
-                float e0 = expf(sc[0] - mx), et = expf(st - mx), sum = e0 + et;
+                float e0 = fast_exp(sc[0] - mx), et = fast_exp(st - mx), sum = e0 + et;
 #pragma unroll
-                for (int j = 0; j < DEN_MAXTOK - 2; ++j) if (j < N) { sc[1 + j] = expf(sc[1 + j] - mx); sum += sc[1 + j]; }
-                const float inv = 1.f / sum;
+                for (int j = 0; j < DEN_MAXTOK - 2; ++j) if (j < N) { sc[1 + j] = fast_exp(sc[1 + j] - mx); sum += sc[1 + j]; }
+                const float inv = fast_rcp(sum);
                 float4 att = f4_scale(v0, e0 * inv);
 #pragma unroll
                 for (int j = 0; j < DEN_MAXTOK - 2; ++j)
@@ -650,19 +690,19 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                     put_x<WT, MS>(XB, es, 0, lane, att);
                 }
             }
-            __syncthreads();
+            __syncthreads(); DEN_DBG(0);
             if constexpr (!FOLD) {
                 // ---- out_proj + residual + norm1
-                gemv_stream<WT, V, MS, G_OUTP, false>(ring, tid, wg, mo, nskip, xin, PART);
+                gemv_stream<WT, V, MS, G_OUTP, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
                 if (epi) {
                     const float4 v = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_out_b + 4 * lane)));
                     xr = wave_ln(v, v_n1w, v_n1b, lane);
                     put_x<WT, MS>(XB, es, 0, lane, xr);
                 }
-                __syncthreads();
+                __syncthreads(); DEN_DBG(0);
             }
             // ---- linear1 + relu  (N = 1024, one k-slice)
-            gemv_stream<WT, V, MS, G_L1, false>(ring, tid, wg, mo, nskip, xin, PART);
+            gemv_stream<WT, V, MS, G_L1, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
             if (epi) {
 #pragma unroll
                 for (int j = 0; j < FF_SA / 256; ++j) {
@@ -670,9 +710,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                     put_x<WT, MS>(XB, es, 256 * j, lane, make_float4(fmaxf(h.x, 0.f), fmaxf(h.y, 0.f), fmaxf(h.z, 0.f), fmaxf(h.w, 0.f)));
                 }
             }
-            __syncthreads();
+            __syncthreads(); DEN_DBG(0);
             // ---- linear2 + residual + norm2, then ca_block (mdiff_transformer.py:219-239, 152-163)
-            gemv_stream<WT, V, MS, G_L2, false>(ring, tid, wg, mo, nskip, xin, PART);
+            gemv_stream<WT, V, MS, G_L2, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
             if (epi) {
                 const float4 v = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_l2b + 4 * lane)));
                 xr = wave_ln(v, v_n2w, v_n2b, lane);
@@ -684,14 +724,14 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                     put_x<WT, MS>(XB, es, 0, lane, xr);
                 }
             }
-            __syncthreads();
+            __syncthreads(); DEN_DBG(0);
             if constexpr (CAQ) {
-                gemv_stream<WT, V, MS, G_CAQ, false>(ring, tid, wg, mo, nskip, xin, PART);
+                gemv_stream<WT, V, MS, G_CAQ, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
                 if (epi) {
                     const float4 qv = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_caq_b + 4 * lane));
                     const float mx = seg_reduce<true>(fmaxf(fmaxf(qv.x, qv.y), fmaxf(qv.z, qv.w)), seg);
-                    const float4 e = make_float4(expf(qv.x - mx), expf(qv.y - mx), expf(qv.z - mx), expf(qv.w - mx));
-                    const float inv = 1.f / seg_reduce<false>(e.x + e.y + e.z + e.w, seg);
+                    const float4 e = make_float4(fast_exp(qv.x - mx), fast_exp(qv.y - mx), fast_exp(qv.z - mx), fast_exp(qv.w - mx));
+                    const float inv = fast_rcp(seg_reduce<false>(e.x + e.y + e.z + e.w, seg));
                     const float4 qc = f4_scale(e, inv);                               // softmax over head_dim (:231)
                     // keys: softmax over the N tokens, per dim (:232)
                     float4 kr[DEN_MAXTOK - 2];
@@ -706,48 +746,52 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
 #pragma unroll
                     for (int j = 0; j < DEN_MAXTOK - 2; ++j)
                         if (j < N) {
-                            kr[j] = make_float4(expf(kr[j].x - kmx.x), expf(kr[j].y - kmx.y), expf(kr[j].z - kmx.z), expf(kr[j].w - kmx.w));
+                            kr[j] = make_float4(fast_exp(kr[j].x - kmx.x), fast_exp(kr[j].y - kmx.y), fast_exp(kr[j].z - kmx.z), fast_exp(kr[j].w - kmx.w));
                             ks = f4_add(ks, kr[j]);
                         }
+                    const float4 rks = make_float4(fast_rcp(ks.x), fast_rcp(ks.y), fast_rcp(ks.z), fast_rcp(ks.w));
                     float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int j = 0; j < DEN_MAXTOK - 2; ++j)
                         if (j < N) {
-                            const float4 kc = make_float4(kr[j].x / ks.x, kr[j].y / ks.y, kr[j].z / ks.z, kr[j].w / ks.w);
+                            const float4 kc = make_float4(kr[j].x * rks.x, kr[j].y * rks.y, kr[j].z * rks.z, kr[j].w * rks.w);
                             const float dot = seg_reduce<false>(f4_dot(qc, kc), seg);                      // q . k_n per head
                             y = f4_fma(dot, ld4(CT + j * 1024 + 768 + 4 * lane), y);                       // (q k^T) v  (:236-237)
                         }
                     const float4 hh = f4_adaln(wave_ln(y, v_csnw, v_csnb, lane), ld4(TTS + 512 + 4 * lane), ld4(TTS + 768 + 4 * lane));
                     put_x<WT, MS>(XB, es, 0, lane, f4_silu(hh));
                 }
-                __syncthreads();
+                __syncthreads(); DEN_DBG(0);
                 // ---- proj_out.out_layers + residual
-                gemv_stream<WT, V, MS, G_CAO, false>(ring, tid, wg, mo, nskip, xin, PART);
+                gemv_stream<WT, V, MS, G_CAO, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
                 if (epi) {
                     xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_cao_b + 4 * lane)));
                     put_x<WT, MS>(XB, es, 0, lane, xr);
                 }
-                __syncthreads();
+                __syncthreads(); DEN_DBG(0);
             }
             // ---- ffn.linear1 + gelu  (N = 128, four k-slices: lanes 0..31 hold 4 outputs each)
-            gemv_stream<WT, V, MS, G_F1, false>(ring, tid, wg, mo, nskip, xin, PART);
+            gemv_stream<WT, V, MS, G_F1, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
+            // request the next layer's operands (LDS-DMA into the other half of the double buffer) here, in a short
+            // stage where the fill path has slack; the epilogue waves are busy and take no part
+            if (!epi) stage_dma<MS, CAQ, MS>(wave, lane, STG + (cur ^ 1) * stg_sz, vp, Ln, A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW, ln, A, b, N,
+                                             A.trow_per_sample ? 0 : (ln == 0 ? step_next : step), ca_R);
             if (epi && lane < FF_D / 4) {
                 const float4 g = f4_add(gemv_out<WT, MS, G_F1>(PART, es, 0, lane), ld4(v_f1b + 4 * lane));
-                put_x<WT, MS>(XB, es, 0, lane, make_float4(act_apply(g.x, SEEME_ACT_GELU), act_apply(g.y, SEEME_ACT_GELU),
-                                                act_apply(g.z, SEEME_ACT_GELU), act_apply(g.w, SEEME_ACT_GELU)));
+                put_x<WT, MS>(XB, es, 0, lane, make_float4(fast_gelu(g.x), fast_gelu(g.y), fast_gelu(g.z), fast_gelu(g.w)));
             }
-            __syncthreads();
+            __syncthreads(); DEN_DBG(0);
             // ---- ffn.linear2 -> AdaLN
-            gemv_stream<WT, V, MS, G_F2, false>(ring, tid, wg, mo, nskip, xin, PART);
+            gemv_stream<WT, V, MS, G_F2, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
             if (epi) {
                 const float4 y2 = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_f2b + 4 * lane));
                 const float4 hh = f4_adaln(wave_ln(y2, v_fsnw, v_fsnb, lane), ld4(TTS + 1024 + 4 * lane), ld4(TTS + 1280 + 4 * lane));
                 put_x<WT, MS>(XB, es, 0, lane, f4_silu(hh));
             }
-            __syncthreads();
+            __syncthreads(); DEN_DBG(0);
             // ---- ffn.proj_out.out_layers + residual; its epilogue also prepares the input of the next layer
             //      (or, after the last layer, runs the stack norm and the scheduler step)
-            gemv_stream<WT, V, MS, G_FO, true>(ring, tid, wg, mo, nskip, xin, PART);
+            gemv_stream<WT, V, MS, G_FO, true>(ring, tid, wg, mo, nskip, xin, PART, epi);
             if (l + 1 < SEEME_DEN_NL) {
                 if (epi) {
                     xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_fo_b + 4 * lane)));
@@ -755,7 +799,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                     put_x<WT, MS>(XB, es, 0, lane, xr);
                     if (nskip) put_x<WT, MS>(XB, es, 256, lane, ld4(keep + (ln == 3 ? 512 : 256)));   // xs.pop(): layer 3 <- layer 1, layer 4 <- layer 0
                 }
-                __syncthreads();
+                __syncthreads(); DEN_DBG(0);
             } else {
                 // ---- stack norm -> model output (cross_attention.py:82-83; mld_denoiser.py:222)
                 float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -765,7 +809,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                     if (MS == 2) st4(PART + es * 256 + 4 * lane, e);
                 }
                 if (MS == 2) {   // classifier-free guidance (mld.py:488-492), uncond (sample 0) first
-                    __syncthreads();
+                    __syncthreads(); DEN_DBG(0);
                     if (epi) {
                         const float4 eu = ld4(PART + 4 * lane), ec = ld4(PART + 256 + 4 * lane);
                         const float g = A.guidance_scale;
@@ -796,12 +840,13 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                     xr = f4_add(nl, ld4(CONSTV + 4 * lane));                         // next step: sample + query_pos
                     put_x<WT, MS>(XB, es, 0, lane, xr);
                 }
-                __syncthreads();
+                __syncthreads(); DEN_DBG(0);
             }
             cur ^= 1;
         }
         row = row_next;
     }
+    DEN_DBG(3);
     if (tid0 < 64) st4(A.out + (size_t)b * 256 + 4 * tid0, ld4(KEEP + 4 * tid0));   // (sample 0 / the guided latent)
     // the last requested chunks are never consumed: keep them from being optimised into dangling loads
 #pragma unroll
@@ -941,3 +986,10 @@ extern "C" int seeme_denoiser_ca_tables(const SeemeDenoiserWeights* w, const flo
     ka.nz = SEEME_DEN_NL; ka.zs_a = (long)rows * 256; ka.zs_w = 256 * 256; ka.zs_b = 256; ka.zs_y = 256;
     return seeme_launch_linear(ka, st);
 }
+
+#ifdef DEN_DBG_TIMES
+extern "C" int seeme_debug_den_times(unsigned long long* host, int n) {
+    SEEME_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(den_dbg_times), sizeof(unsigned long long) * (size_t)(n < 512 ? n : 512)));
+    return 0;
+}
+#endif
