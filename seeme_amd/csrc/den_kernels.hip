@@ -512,15 +512,16 @@ struct DenKArgs {
 // wave-instruction spread over the non-epilogue waves.  vmcnt retires in issue order, so once a wave has consumed any weight chunk it requested
 // later, its copies have landed; the barriers of layer l then publish them.  (hipcc does not count the asm
 // DMA: its own vmcnt(N) waits only become slightly longer, never shorter.)
-template <int MS, bool CAQ, int W0>
+template <int MS, bool CAQ, int W0, int PART>   // PART 0: everything, 1: the vector params, 2: the table rows
 __device__ __forceinline__ void stage_dma(int wave, int lane, float* __restrict__ stg, const float* __restrict__ vpg,
                                           const DenLayerOff* __restrict__ L, const float* __restrict__ tt_row, int l,
                                           const SeemeSampleArgs& A, int b, int N, int ca_r, int ca_R) {
     const uint32_t base = lds_addr_of(stg);
     const int ncond = 31 + 4 * MS * N;
     const int total = ncond + (CAQ ? 0 : MS);
+    const int c_lo = (PART == 2) ? 25 : 0, c_hi = (PART == 1) ? 25 : total;
 #pragma unroll 1
-    for (int c = wave - W0; c < total; c += DEN_THREADS / 64 - W0) {   // waves W0 .. 7 share the copies
+    for (int c = c_lo + wave - W0; c < c_hi; c += DEN_THREADS / 64 - W0) {   // waves W0 .. 7 share the copies
         const float* src;
         int dst, lanes = 64;
         if (c < 25) {                       // VP_LAYER = 24.5 KiB of vector params
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     {
         for (int i = tid0; i < 192; i += DEN_THREADS)
             st4(CONSTV + 4 * i, i < 64 ? ld4(vp + lay->pe0 + 4 * i) : (i < 128 ? ld4(vp + lay->fnw + 4 * (i - 64)) : ld4(vp + lay->fnb + 4 * (i - 128))));
-        stage_dma<MS, CAQ, 0>(wave, lane, STG, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b, N, 0, ca_R);
+        stage_dma<MS, CAQ, 0, 0>(wave, lane, STG, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b, N, 0, ca_R);
         if (WT::MFMA) for (int i = tid0; i < XB_FLOATS(true, MS) / 4; i += DEN_THREADS) st4(XB + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
         wait_vmcnt0();
         __syncthreads();
@@ -772,10 +773,10 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             }
             // ---- ffn.linear1 + gelu  (N = 128, four k-slices: lanes 0..31 hold 4 outputs each)
             gemv_stream<WT, V, MS, G_F1, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
-            // request the next layer's operands (LDS-DMA into the other half of the double buffer) here, in a short
-            // stage where the fill path has slack; the epilogue waves are busy and take no part
-            if (!epi) stage_dma<MS, CAQ, MS>(wave, lane, STG + (cur ^ 1) * stg_sz, vp, Ln, A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW, ln, A, b, N,
-                                             A.trow_per_sample ? 0 : (ln == 0 ? step_next : step), ca_R);
+            // request the next layer's operands (LDS-DMA into the other half of the double buffer) here, in the short
+            // stages where the fill path has slack; the epilogue waves are busy and take no part
+            if (!epi) stage_dma<MS, CAQ, MS, 1>(wave, lane, STG + (cur ^ 1) * stg_sz, vp, Ln, A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW, ln, A, b, N,
+                                                A.trow_per_sample ? 0 : (ln == 0 ? step_next : step), ca_R);
             if (epi && lane < FF_D / 4) {
                 const float4 g = f4_add(gemv_out<WT, MS, G_F1>(PART, es, 0, lane), ld4(v_f1b + 4 * lane));
                 put_x<WT, MS>(XB, es, 0, lane, make_float4(fast_gelu(g.x), fast_gelu(g.y), fast_gelu(g.z), fast_gelu(g.w)));
@@ -783,6 +784,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             __syncthreads(); DEN_DBG(0);
             // ---- ffn.linear2 -> AdaLN
             gemv_stream<WT, V, MS, G_F2, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
+            if (!epi) stage_dma<MS, CAQ, MS, 2>(wave, lane, STG + (cur ^ 1) * stg_sz, vp, Ln, A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW, ln, A, b, N,
+                                                A.trow_per_sample ? 0 : (ln == 0 ? step_next : step), ca_R);
             if (epi) {
                 const float4 y2 = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_f2b + 4 * lane));
                 const float4 hh = f4_adaln(wave_ln(y2, v_fsnw, v_fsnb, lane), ld4(TTS + 1024 + 4 * lane), ld4(TTS + 1280 + 4 * lane));
