@@ -95,7 +95,13 @@ struct LinearHArgs {
     const uint4* wp; int kstride; int ntiles;
     int qkv_mode;               // 1: N = 768 -> q|k fp16 rows [M][512] and V transposed [B][256][spv]
     unsigned short* qk; unsigned short* vt; int S, spv;
+    int fast;                   // (set by the launcher) float4 staging straight to fp16: no fp32 staging tile in LDS
 };
+__host__ __device__ static inline bool linear_h_fast(const SeemeLinearArgs& a) {
+    return (a.pre_ln_w == nullptr) && ((a.K & 3) == 0) && ((a.K1 & 3) == 0) && ((a.lda & 3) == 0) &&
+           ((reinterpret_cast<size_t>(a.A) & 15) == 0) &&
+           (a.A2 == nullptr || (((a.lda2 & 3) == 0) && ((reinterpret_cast<size_t>(a.A2) & 15) == 0)));
+}
 
 __global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -104,15 +110,13 @@ __global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Kp = (a.K + 31) & ~31;
     const int lda_f = Kp + LDS_PAD, lda_h = Kp + HPAD;
-    float* Af = smem;                                                  // [32][Kp+8] fp32 staging (pre-LN / act)
-    float* Cs = Af + TILE_M * lda_f;                                   // [32][264]
+    const bool fast = ha.fast != 0;
+    float* Af = smem;                                                  // [32][Kp+8] fp32 staging (pre-LN / act); absent in the fast path
+    float* Cs = fast ? smem : Af + TILE_M * lda_f;                     // [32][264]
     unsigned short* Ah = reinterpret_cast<unsigned short*>(Cs + TILE_M * (CH_N + LDS_PAD));   // [32][Kp+16] fp16
     const int ldc = CH_N + LDS_PAD;
     const int m0 = blockIdx.x * TILE_M, cn0 = blockIdx.y * CH_N;
 
-    const bool fast = (a.pre_ln_w == nullptr) && ((a.K & 3) == 0) && ((a.K1 & 3) == 0) && ((a.lda & 3) == 0) &&
-                      ((reinterpret_cast<size_t>(a.A) & 15) == 0) &&
-                      (a.A2 == nullptr || (((a.lda2 & 3) == 0) && ((reinterpret_cast<size_t>(a.A2) & 15) == 0)));
     if (fast) {   // float4 in, 4 halves out, no fp32 staging tile
         const int Kp4 = Kp >> 2, K4 = a.K >> 2;
         for (int idx = tid; idx < TILE_M * Kp4; idx += 256) {
@@ -226,10 +230,13 @@ static int launch_linear_h(const LinearHArgs& ha, hipStream_t st) {
     const int Kp = (a.K + 31) & ~31;
     if (Kp > 512) return seeme_fail("linear_h: K > 512 not supported");
     if (a.ln_w && a.N != 256) return seeme_fail("linear_h: fused LayerNorm needs N == 256");
-    const size_t lds = (size_t)(TILE_M * (Kp + LDS_PAD) + TILE_M * (CH_N + LDS_PAD)) * 4 + (size_t)TILE_M * (Kp + HPAD) * 2;
+    LinearHArgs h2 = ha;
+    h2.fast = linear_h_fast(a) ? 1 : 0;
+    // the fast path needs no fp32 staging tile: 51 KB (K = 256) instead of 85 KB, i.e. 3 workgroups per CU instead of 1
+    const size_t lds = (size_t)((h2.fast ? 0 : TILE_M * (Kp + LDS_PAD)) + TILE_M * (CH_N + LDS_PAD)) * 4 + (size_t)TILE_M * (Kp + HPAD) * 2;
     dim3 grid((a.M + TILE_M - 1) / TILE_M, (a.N + CH_N - 1) / CH_N);
     SEEME_HIP(hipFuncSetAttribute((const void*)k_linear_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_linear_h, grid, dim3(256), lds, st, ha);
+    hipLaunchKernelGGL(k_linear_h, grid, dim3(256), lds, st, h2);
     return seeme_check_launch("k_linear_h");
 }
 
@@ -352,9 +359,10 @@ __global__ __launch_bounds__(256) void k_ffn_block_h(const FfnHArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int ld = 256 + LDS_PAD, ldh = 256 + HPAD;
     float* Xs = smem;                                                      // [32][264] fp32 block input (residual)
-    float* Cs = Xs + TILE_M * ld;                                          // [32][264] fp32 output tile
-    unsigned short* Xh = reinterpret_cast<unsigned short*>(Cs + TILE_M * ld);   // [32][272] fp16 A operand
-    unsigned short* Hh = Xh + TILE_M * ldh;                                // [32][FF+16] hidden (FF = 128)
+    unsigned short* Hh = reinterpret_cast<unsigned short*>(Xs + TILE_M * ld);   // [32][FF+16] hidden (FF = 128)
+    float* Cs = reinterpret_cast<float*>(Hh + TILE_M * (a.FF + HPAD));     // [32][264] fp32 output tile ...
+    unsigned short* Xh = reinterpret_cast<unsigned short*>(Cs);            // ... whose head first holds the [32][272] fp16 A operand
+                                                                           // (dead once the hidden layer is formed: 77 KB, 2 workgroups/CU)
     const int m0 = blockIdx.x * TILE_M;
     for (int rr = 0; rr < 8; ++rr) {
         const int row = wave * 8 + rr, m = m0 + row;
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(256) void k_ffn_block_h(const FfnHArgs a) {
 
 static int launch_ffn_h(const FfnHArgs& a, hipStream_t st) {
     if (a.FF != 128) return seeme_fail("ffn_h: FF must be 128 (hard-coded in the reference VAE, mld_vae.py:53)");
-    const size_t lds = (size_t)2 * TILE_M * (256 + LDS_PAD) * 4 + (size_t)TILE_M * (256 + HPAD) * 2 + (size_t)TILE_M * (a.FF + HPAD) * 2;
+    const size_t lds = (size_t)2 * TILE_M * (256 + LDS_PAD) * 4 + (size_t)TILE_M * (a.FF + HPAD) * 2;
     dim3 grid((a.M + TILE_M - 1) / TILE_M);
     SEEME_HIP(hipFuncSetAttribute((const void*)k_ffn_block_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_ffn_block_h, grid, dim3(256), lds, st, a);
