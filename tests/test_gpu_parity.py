@@ -409,6 +409,29 @@ def test_denoiser_multihead_vs_oracle(dev, H):
     assert rel_err(y.cpu().numpy(), ref) < TOL_F32
 
 
+@pytest.mark.parametrize("wd,tol", [("fp32", 5e-4), ("fp16", 6e-3), ("bf16", TOL_BF16W)])
+@pytest.mark.parametrize("H", [1, 2])
+@pytest.mark.parametrize("N", [1, 3])
+@pytest.mark.parametrize("cfg", [False, True])
+def test_sampling_kernel_variants(dev, wd, tol, H, N, cfg):
+    """Every compiled variant of the persistent kernel (weight type x CFG pair x one/many condition tokens x
+    folded/unfolded out_proj) against the oracle loop, 6 DDIM steps, B = 3."""
+    from seeme_amd.mld_denoiser import MldDenoiser
+    den = load_recipe_(MldDenoiser(ablation(), condition=["text", "scene", "interactee"], latent_dim=[1, 256], ff_size=128,
+                                   num_layers=5, num_heads=H, weight_dtype=wd)).to(dev).eval()
+    rng = np.random.default_rng(100 * H + 10 * N + int(cfg))
+    B, steps, gs = 3, 6, (2.5 if cfg else 1.0)
+    lat = rng.standard_normal((B, 1, 256)).astype(np.float32)
+    cond = rng.standard_normal(((2 * B if cfg else B), N, 256)).astype(np.float32)
+    P = recipe_state_dict(shapes.denoiser_shapes())
+    ref = O.diffusion_reverse(P, cond, lat, steps, guidance_scale=gs, nhead=H)
+    sch = _sched()
+    sch.set_timesteps(steps)
+    out = den.sample_loop(torch.from_numpy(lat).to(dev), torch.from_numpy(cond).to(dev), sch, guidance_scale=gs)
+    err = rel_err(out.cpu().numpy(), ref)
+    assert err < tol, f"{wd} H={H} N={N} cfg={cfg}: rel err {err:.3e}"
+
+
 def test_vae_extreme_shapes(dev):
     """B = 1, the longest sequence the learned PE allows (T = 498 -> 500 tokens), and a length-1 sequence in a batch."""
     P = recipe_state_dict(shapes.vae_shapes(75))
