@@ -19,6 +19,7 @@
 #include <utility>
 
 #define DEN_THREADS 512
+#define SEEME_DEN_PAIR_ABOVE 256   // batches above this run two independent samples per workgroup
 #define DEN_MAXTOK 6   // 1 latent + N<=4 condition tokens + 1 time token
 #define DEN_R 4        // register ring: chunks of the weight stream in flight per lane
 #define DEN_CH 8       // 16-B vectors per lane per chunk (ring = 4 x 8 x 4 = 128 VGPRs)
@@ -512,6 +513,21 @@ struct DenKArgs {
 // wave-instruction spread over the non-epilogue waves.  vmcnt retires in issue order, so once a wave has consumed any weight chunk it requested
 // later, its copies have landed; the barriers of layer l then publish them.  (hipcc does not count the asm
 // DMA: its own vmcnt(N) waits only become slightly longer, never shorter.)
+// Which rows of the per-sample tables / latents the MS samples of workgroup b use.  CFG pair (A.cfg): both share
+// latent b; sample 0 = unconditional branch (first half of ctab, mld.py:489), sample 1 = conditional (second half).
+// Independent samples (MS = 2 without CFG, batches larger than the chip): samples MS*b + s, clamped to B - 1.
+template <int MS>
+__device__ __forceinline__ int den_lat_index(const SeemeSampleArgs& A, int b, int s) {
+    if (MS == 1 || A.cfg) return b;
+    const int i = MS * b + s;
+    return i < A.B ? i : A.B - 1;
+}
+template <int MS>
+__device__ __forceinline__ int den_cond_index(const SeemeSampleArgs& A, int b, int s) {
+    if (MS == 2 && A.cfg) return s == 1 ? A.B + b : b;
+    return den_lat_index<MS>(A, b, s);
+}
+
 template <int MS, bool CAQ, int W0, int PART>   // PART 0: everything, 1: the vector params, 2: the table rows
 __device__ __forceinline__ void stage_dma(int wave, int lane, float* __restrict__ stg, const float* __restrict__ vpg,
                                           const DenLayerOff* __restrict__ L, const float* __restrict__ tt_row, int l,
@@ -532,12 +548,12 @@ __device__ __forceinline__ void stage_dma(int wave, int lane, float* __restrict_
             src = tt_row + 2560 + l * 1024 + (c - 27) * 256; dst = VP_LAYER + 512 + (c - 27) * 256;
         } else if (!CAQ && c >= ncond) {    // one condition token: the tabulated ca_block term of (sample, row, layer)
             const int sidx = c - ncond;
-            const int bc = (MS == 2 && sidx == 1) ? A.B + b : b;
+            const int bc = den_cond_index<MS>(A, b, sidx);
             src = A.catab + (((size_t)bc * ca_R + ca_r) * SEEME_DEN_NL + l) * 256; dst = VP_LAYER + STG_TT + MS * N * 1024 + sidx * 256;
         } else {                            // condition tokens: sa K|V (512) | ca key|value (512) per (sample, token)
             const int j = c - 31, sn = j >> 2, q = j & 3;
             const int s = sn / N, n = sn - s * N;
-            const int bc = (MS == 2 && s == 1) ? A.B + b : b;     // CFG: s 0 = uncond (first half), s 1 = cond
+            const int bc = den_cond_index<MS>(A, b, s);
             src = A.ctab + ((size_t)bc * N + n) * SEEME_CROW + (q < 2 ? l * 512 + q * 256 : 2560 + l * 512 + (q - 2) * 256);
             dst = VP_LAYER + STG_TT + sn * 1024 + q * 256;
         }
@@ -586,7 +602,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     const float sa_scale = 1.f / sqrtf((float)(256 / H));   // (once per kernel)
     if (epi) __builtin_amdgcn_s_setprio(3);      // the chain of dependent epilogues is the critical path
     float* const keep = KEEP + es * 768 + 4 * lane;   // [0] latent, [256] layer-0 output, [512] layer-1 output
-    float4 xr = ld4(A.latents + (size_t)b * 256 + 4 * lane);
+    const int bl = den_lat_index<MS>(A, b, es);          // this epilogue wave's row of latents / noise / out
+    float4 xr = ld4(A.latents + (size_t)bl * 256 + 4 * lane);
     if (epi) st4(keep, xr);
 
     // ---- prologue: constants, layer 0 operands, first input vector, first DEN_R chunks
@@ -813,7 +830,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                 }
                 if (MS == 2) {   // classifier-free guidance (mld.py:488-492), uncond (sample 0) first
                     __syncthreads(); DEN_DBG(0);
-                    if (epi) {
+                    if (epi && A.cfg) {
                         const float4 eu = ld4(PART + 4 * lane), ec = ld4(PART + 256 + 4 * lane);
                         const float g = A.guidance_scale;
                         e = make_float4(eu.x + g * (ec.x - eu.x), eu.y + g * (ec.y - eu.y), eu.z + g * (ec.z - eu.z), eu.w + g * (ec.w - eu.w));
@@ -826,7 +843,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                     const float* __restrict__ c = A.coef + (size_t)step * 8;
                     const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], clip = c[6], ptype = c[7];
                     float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (A.noise != nullptr) nz = ld4(A.noise + ((size_t)step * A.B + b) * 256 + 4 * lane);
+                    if (A.noise != nullptr) nz = ld4(A.noise + ((size_t)step * A.B + bl) * 256 + 4 * lane);
                     const float4 lat = ld4(keep);
                     const float xs[4] = {lat.x, lat.y, lat.z, lat.w}, es4[4] = {e.x, e.y, e.z, e.w}, ns[4] = {nz.x, nz.y, nz.z, nz.w};
                     float o[4];
@@ -850,7 +867,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
         row = row_next;
     }
     DEN_DBG(3);
-    if (tid0 < 64) st4(A.out + (size_t)b * 256 + 4 * tid0, ld4(KEEP + 4 * tid0));   // (sample 0 / the guided latent)
+    // CFG pair: one guided latent (both waves hold it, wave 0 writes); independent samples: one row each
+    if (epi && (es == 0 || (!A.cfg && MS * b + es < A.B))) st4(A.out + (size_t)bl * 256 + 4 * lane, ld4(keep));
     // the last requested chunks are never consumed: keep them from being optimised into dangling loads
 #pragma unroll
     for (int s = 0; s < DEN_R; ++s) asm volatile("" ::"v"(ring.r[s][0].x));
@@ -862,10 +880,11 @@ static size_t den_lds_bytes(int MS, int N, bool mfma) {
 
 template <typename WT, int MS, int V>
 static int launch_den(const DenKArgs& ka, hipStream_t st) {
+    const int chains = (MS == 2 && !ka.s.cfg) ? (ka.s.B + 1) / 2 : ka.s.B;
     const size_t lds = den_lds_bytes(MS, ka.s.N, WT::MFMA);
     if (lds > 160 * 1024) return seeme_fail("denoiser_sample: LDS budget exceeded");
     SEEME_HIP(hipFuncSetAttribute((const void*)k_den_sample<WT, MS, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_den_sample<WT, MS, V>), dim3(ka.s.B), dim3(DEN_THREADS), lds, st, ka);
+    hipLaunchKernelGGL((k_den_sample<WT, MS, V>), dim3(chains), dim3(DEN_THREADS), lds, st, ka);
     return seeme_check_launch("k_den_sample");
 }
 template <typename WT, int MS>
@@ -876,7 +895,10 @@ static int launch_den_ms(const DenKArgs& ka, bool fold, hipStream_t st) {
 }
 template <typename WT>
 static int launch_den_wt(const DenKArgs& ka, bool fold, hipStream_t st) {
-    return ka.s.cfg ? launch_den_ms<WT, 2>(ka, fold, st) : launch_den_ms<WT, 1>(ka, fold, st);
+    // two samples per workgroup: a CFG pair, or -- when there are more samples than CUs and all share the step's
+    // timestep -- two independent samples behind one weight stream (the matrix-core operand has rows to spare)
+    const bool pair = ka.s.cfg || (ka.s.B > SEEME_DEN_PAIR_ABOVE && !ka.s.trow_per_sample);
+    return pair ? launch_den_ms<WT, 2>(ka, fold, st) : launch_den_ms<WT, 1>(ka, fold, st);
 }
 
 extern "C" int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeSampleArgs* a, void* stream) {

@@ -432,6 +432,27 @@ def test_sampling_kernel_variants(dev, wd, tol, H, N, cfg):
     assert err < tol, f"{wd} H={H} N={N} cfg={cfg}: rel err {err:.3e}"
 
 
+@pytest.mark.parametrize("wd", ["fp32", "fp16"])
+def test_large_batch_pairs_match_single_chains(dev, wd):
+    """Batches above 256 run two independent samples per workgroup (one weight stream); the result must equal the
+    one-sample-per-workgroup path (itself pinned to the oracle above).  B odd: the last workgroup has one sample."""
+    den = make_den(dev, weight_dtype=wd)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    B, steps = 2 * 256 + 3, 4
+    lat = torch.randn(B, 1, 256, generator=g).to(dev)
+    cond = torch.randn(B, 1, 256, generator=g).to(dev)
+    noise = torch.randn(steps, B, 256, generator=g).to(dev)
+    sch = _sched("ddpm")
+    sch.set_timesteps(steps)
+    full = den.sample_loop(lat, cond, sch, step_noise=noise)                       # pairs
+    parts = [den.sample_loop(lat[i:i + 200], cond[i:i + 200], sch, step_noise=noise[:, i:i + 200].contiguous())
+             for i in range(0, B, 200)]                                            # single chains
+    ref = torch.cat(parts, dim=1)
+    assert full.shape == ref.shape == (1, B, 256)
+    tol = 1e-5 if wd == "fp32" else 1e-4     # same arithmetic per sample; fp32 path differs only by accumulation order
+    assert rel_err(full.cpu().numpy(), ref.cpu().numpy()) < tol
+
+
 def test_vae_extreme_shapes(dev):
     """B = 1, the longest sequence the learned PE allows (T = 498 -> 500 tokens), and a length-1 sequence in a batch."""
     P = recipe_state_dict(shapes.vae_shapes(75))
