@@ -137,13 +137,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    # rehearsal on a one-GPU box: SEEME_BENCH_BACKEND=gloo SEEME_BENCH_DEVICE=0 puts every rank on one card
+    backend = os.environ.get("SEEME_BENCH_BACKEND", "nccl")
+    if "SEEME_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["SEEME_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist_on = world > 1
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     B = args.batch
     vae, den, sch = build_models(dev, args.weights, args.vae)
@@ -176,7 +183,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist_on:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert os.environ.get("SEEME_DEBUG_NOCHECK") or torch.isfinite(out).all()   # (debug timing builds produce garbage)
