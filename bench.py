@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--weights", default="fp16", choices=["fp32", "bf16", "fp16"], help="denoiser weight image dtype")
     ap.add_argument("--vae", default="fp16", choices=["fp32", "fp16"], help="VAE MFMA operand type (fp32 = exact parity path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the passes are dealt over (each with its own model instance); 1 = the named configuration, "
+                         ">1 = several B-sized batches in flight on one GPU (a B=32 pass occupies 32 of 256 CUs)")
     ap.add_argument("--scheduler", default="ddim", choices=["ddim", "ddpm"], help="ddpm = 1000-step ancestral sampling (BASELINE configs[4])")
     args = ap.parse_args()
 
@@ -153,7 +156,10 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     B = args.batch
-    vae, den, sch = build_models(dev, args.weights, args.vae)
+    S = max(1, args.streams)
+    models = [build_models(dev, args.weights, args.vae) for _ in range(S)]
+    vae, den, sch = models[0]
+    streams = [torch.cuda.Stream() for _ in range(S)]     # (side streams only: the legacy default stream serialises with all others)
     n_infer = DDIM_STEPS
     if args.scheduler == "ddpm":
         from seeme_amd.schedulers import DDPMScheduler
@@ -161,13 +167,21 @@ def main():
                             variance_type="fixed_small", clip_sample=False)
         sch.set_timesteps(1000)
         n_infer = 1000
+        models = [(v, d, sch) for v, d, _ in models]
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     motion = torch.randn(B, T_FRAMES, NFEATS, generator=g).to(dev)
     latents = torch.randn(B, 1, 256, generator=g).to(dev)
     lengths = [T_FRAMES] * B
 
-    for _ in range(args.warmup):
-        one_pass(vae, den, sch, motion, latents, lengths)
+    def run_pass(i, ev=None):
+        v, d, sc = models[i % S]
+        if S == 1:
+            return one_pass(v, d, sc, motion, latents, lengths, ev)
+        with torch.cuda.stream(streams[i % S]):
+            return one_pass(v, d, sc, motion, latents, lengths, ev)
+
+    for i in range(max(args.warmup, S if S > 1 else 0)):
+        run_pass(i)
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -176,7 +190,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = one_pass(vae, den, sch, motion, latents, lengths, evs[i])
+        out = run_pass(i, evs[i])
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -214,7 +228,8 @@ def main():
             "config": {"workload": f"config_mld_egobody interactee-only: VAE encode -> 50-step DDIM -> VAE decode, "
                                    f"B={B}/GPU, T=196, nfeats=132, random-init recipe weights",
                        "batch_per_gpu": B, "seq_len": T_FRAMES, "ddim_steps": n_infer,
-                       "parallelism": f"dp{world} (independent shards, no collective on the data path)"},
+                       "parallelism": f"dp{world} (independent shards, no collective on the data path)"
+                                      + (f", {S} batches in flight per GPU" if S > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_den_sample (persistent DDIM loop)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.weights, B, n_infer),

@@ -21,6 +21,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--points", type=int, default=20000)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--scene-precision", default="fp32", choices=["fp32", "bf16"])
+ap.add_argument("--graph", action="store_true", help="capture the whole step as one hipGraph and time replays")
 args = ap.parse_args()
 rank, ws, local = D.init_from_env()
 dev = torch.device("cuda", local)
@@ -35,6 +36,19 @@ model = model.to(dev).train()
 D.broadcast_parameters(model)
 batch = dm.batch(args.batch, idx=rank, with_scene=True)
 ev = lambda: torch.cuda.Event(enable_timing=True)
+if args.graph:
+    replay = model.capture_training_step(batch)
+    torch.cuda.synchronize()
+    for it in range(args.steps + 1):
+        e0, e1 = ev(), ev()
+        e0.record()
+        loss = replay()
+        e1.record()
+        torch.cuda.synchronize()
+        if it and rank == 0:
+            print(json.dumps({"step": it, "loss": round(float(loss.detach()), 5), "graph_replay_ms": round(e0.elapsed_time(e1), 2), "B": args.batch,
+                              "points": args.points, "world": ws, "scene_precision": args.scene_precision}))
+    sys.exit(0)
 for it in range(args.steps + 1):
     e = [ev() for _ in range(4)]
     e[0].record()

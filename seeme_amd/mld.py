@@ -44,9 +44,11 @@ class MLDLosses:
             raise ValueError(f"Stage {self.stage} not supported")
         self.sums: Dict[str, float] = {}
         self.count = 0
+        self.accumulate = True
 
     def _acc(self, name, val, weight):
-        self.sums[name] = self.sums.get(name, 0.0) + float(val.detach())
+        if self.accumulate:    # running sums stay on the device: no host sync per step (compute() converts)
+            self.sums[name] = self.sums.get(name, 0.0) + val.detach()
         return weight * val
 
     @staticmethod
@@ -54,7 +56,8 @@ class MLDLosses:
         pg, pp = gt[:, :, [0]], pred[:, :, [0]]
         return gt - pg, pred - pp, pg, pp
 
-    def update(self, rs):
+    def update(self, rs, accumulate: bool = True):
+        self.accumulate = accumulate
         L = self.cfg.LOSS
         total = 0.0
         mse = nn.functional.mse_loss
@@ -74,12 +77,13 @@ class MLDLosses:
                 total = total + self._acc("inst_loss", mse(rs["noise_pred"], rs["noise"]), 1.0)
             else:
                 total = total + self._acc("x_loss", mse(rs["pred"], rs["latent"]), 1.0)
-        self.sums["total"] = self.sums.get("total", 0.0) + float(total.detach())
-        self.count += 1
+        if accumulate:
+            self.sums["total"] = self.sums.get("total", 0.0) + total.detach()
+            self.count += 1
         return total
 
     def compute(self):
-        return {k: v / max(self.count, 1) for k, v in self.sums.items()}
+        return {k: float(v) / max(self.count, 1) for k, v in self.sums.items()}
 
     def reset(self):
         self.sums, self.count = {}, 0
@@ -239,10 +243,10 @@ class MLD(nn.Module):
         self.times: List[float] = []
 
     # ------------------------------------------------------------------ optimiser (mld.py:292-299, base.py:157-158)
-    def configure_optimizers(self):
+    def configure_optimizers(self, capturable: bool = False):
         if self.optimizer is None:
             params = [p for p in self.parameters() if p.requires_grad]
-            self.optimizer = torch.optim.AdamW(params, lr=self.cfg.TRAIN.OPTIM.LR)
+            self.optimizer = torch.optim.AdamW(params, lr=self.cfg.TRAIN.OPTIM.LR, capturable=capturable)
             self.sch = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=self.cfg.TRAIN.OPTIM.STEP_SIZE,
                                                        gamma=self.cfg.TRAIN.OPTIM.GAMMA)
         return {"optimizer": self.optimizer}
@@ -456,6 +460,52 @@ class MLD(nn.Module):
 
     def test_step(self, batch, batch_idx=0):
         return self.allsplit_step("test", batch, batch_idx)
+
+    def capture_training_step(self, batch, warmup: int = 3):
+        """One stage-2 training step (frozen HIP encoders, denoiser forward + backward, AdamW) captured as ONE
+        hipGraph on static input buffers -- the launch-bound chain of ~10^3 small kernels replays without host work.
+        Returns replay(new_batch=None) -> loss tensor (static).  World size 1 only captures the optimiser too;
+        with data parallelism the gradient all-reduce and the optimiser step stay eager after the replay."""
+        from . import distributed as D
+        world = D.world()[1]
+        self.configure_optimizers(capturable=True)
+        static = [b.clone() if torch.is_tensor(b) else b for b in batch]
+        losses = self.losses["train"]
+
+        def step():
+            loss = losses.update(self.train_diffusion_forward(static), accumulate=False)
+            loss.backward()
+            if world == 1:
+                self.optimizer.step()
+            return loss
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.optimizer.zero_grad(set_to_none=True)
+                step()
+                if world > 1:
+                    D.allreduce_gradients(self.trainable_parameters())
+                    self.optimizer.step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            static_loss = step()
+
+        def replay(new_batch=None):
+            if new_batch is not None:
+                for dst, src in zip(static, new_batch):
+                    if torch.is_tensor(dst):
+                        dst.copy_(src)
+            graph.replay()
+            if world > 1:
+                D.allreduce_gradients(self.trainable_parameters())
+                self.optimizer.step()
+            return static_loss
+
+        return replay
 
     def optimizer_step(self, loss, world=None):
         """backward -> (data-parallel) gradient all-reduce -> AdamW step; what Lightning + DDP do around

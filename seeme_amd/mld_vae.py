@@ -214,7 +214,17 @@ class MldVae(nn.Module):
 
     @staticmethod
     def _lengths_tensor(lengths, device) -> torch.Tensor:
-        return torch.as_tensor(list(lengths), dtype=torch.int32).to(device, non_blocking=True)
+        # cached per (lengths, device): no host-to-device copy in steady state (and none inside a hipGraph capture)
+        key = (tuple(int(v) for v in lengths), str(device))
+        t = MldVae._LEN_CACHE.get(key)
+        if t is None:
+            if len(MldVae._LEN_CACHE) > 64:
+                MldVae._LEN_CACHE.clear()
+            t = torch.as_tensor(list(key[0]), dtype=torch.int32).to(device)
+            MldVae._LEN_CACHE[key] = t
+        return t
+
+    _LEN_CACHE: dict = {}
 
     # ------------------------------------------------------------------ reference API
     def forward(self, features, lengths: Optional[List[int]] = None):
@@ -249,7 +259,7 @@ class MldVae(nn.Module):
         dist = self.encode_dist(features, lengths)
         mu, logvar = dist[0:1], dist[1:2]
         std = logvar.exp().pow(0.5)                                   # mld_vae.py:190
-        normal = torch.distributions.Normal(mu, std)
+        normal = torch.distributions.Normal(mu, std, validate_args=False)   # (validation would force a host sync)
         latent = normal.rsample()                                     # :192 (RNG stays in torch)
         return latent, normal
 

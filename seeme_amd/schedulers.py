@@ -54,7 +54,11 @@ class _SchedulerBase:
 
     def add_noise(self, original_samples, noise, timesteps):
         """x_t = sqrt(acp[t]) x_0 + sqrt(1-acp[t]) noise, per-sample t (mld.py:604-606)."""
-        acp = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
+        key = (str(original_samples.device), original_samples.dtype)
+        if getattr(self, "_acp_dev_key", None) != key:      # device copy cached: no host-to-device copy per step
+            self._acp_dev = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
+            self._acp_dev_key = key
+        acp = self._acp_dev
         t = timesteps.to(original_samples.device)
         a = acp[t] ** 0.5
         s = (1 - acp[t]) ** 0.5
