@@ -1,13 +1,14 @@
 """Parity of the HIP path (through the C-ABI) against the reference-generated golden fixtures and the
 numpy oracle.  Needs a real MI355X: run with `pytest -m gpu`."""
 import ctypes as C
+import os
 import types
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import REPO, load_golden, rel_err
 from oracle import mld_oracle as O
 from seeme_amd.weights_recipe import load_recipe_, recipe_state_dict
 from seeme_amd import shapes
@@ -517,3 +518,36 @@ def test_vae_fp16_mfma_mode(dev):
         e_dec = rel_err(dec.cpu().numpy(), g["decoded"])
         print(f"fp16-MFMA VAE {name}: mu rel err {e_mu:.3e}, decode rel err {e_dec:.3e}")
         assert e_mu < 2e-2 and e_dec < 2e-2
+
+
+# ----------------------------------------------------------------------------- train.py / test.py equivalents
+@pytest.mark.gpu
+def test_cli_train_resume_and_test(dev, tmp_path):
+    """Two epochs of stage-2 training on synthetic batches, Lightning-layout checkpoints, resume from the newest one,
+    strict reload for testing, metrics file (train.py:26-53,114-123,155-167; test.py:111-152)."""
+    from seeme_amd import cli
+    cfgp = os.path.join(REPO, "configs", "config_mld_egobody.yaml")
+    common = ["--cfg", cfgp, "--batch_size", "4", "--nodebug", "--folder", str(tmp_path), "--frames", "24",
+              "--iters_per_epoch", "2"]
+    r1 = cli.train_main(common + ["--epochs", "2"])
+    ck = sorted(os.listdir(r1["checkpoints"]))
+    assert ck == ["epoch=0.ckpt", "epoch=1.ckpt"] and r1["step"] == 4 and np.isfinite(r1["total"])
+    sd = cli.read_checkpoint(os.path.join(r1["checkpoints"], "epoch=1.ckpt"))["state_dict"]
+    assert any(k.startswith("vae.encoder.") for k in sd) and any(k.startswith("denoiser.encoder.") for k in sd)
+    # resume: continues after the newest checkpoint
+    import yaml
+    rcfg = tmp_path / "resume.yaml"
+    base = yaml.safe_load(open(cfgp))
+    base.setdefault("TRAIN", {})["RESUME"] = r1["folder"]
+    rcfg.write_text(yaml.safe_dump(base))
+    for fn in ("base.yaml",):
+        (tmp_path / fn).write_text(open(os.path.join(REPO, "configs", fn)).read())
+    os.makedirs(tmp_path / "modules", exist_ok=True)
+    for fn in os.listdir(os.path.join(REPO, "configs", "modules")):
+        (tmp_path / "modules" / fn).write_text(open(os.path.join(REPO, "configs", "modules", fn)).read())
+    r2 = cli.train_main(["--cfg", str(rcfg)] + common[2:] + ["--epochs", "3"])
+    assert r2["epoch"] == 2 and r2["step"] == 6 and os.path.exists(os.path.join(r2["checkpoints"], "epoch=2.ckpt"))
+    # test: strict load, metrics json
+    out = cli.test_main(["--cfg", cfgp, "--batch_size", "4", "--folder", str(tmp_path), "--frames", "24", "--test_batches", "2",
+                         "--checkpoint", os.path.join(r2["checkpoints"], "epoch=2.ckpt")])
+    assert np.isfinite(out["Metrics/MPJPE/mean"]) and os.path.exists(out["file"])

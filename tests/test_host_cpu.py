@@ -156,3 +156,43 @@ def test_mld_constructs_from_config_on_cpu():
     for name in ("training_step", "validation_step", "test_step", "allsplit_step", "_diffusion_reverse",
                  "_diffusion_process", "train_vae_forward", "train_diffusion_forward", "ego_eval", "configure_optimizers"):
         assert callable(getattr(m, name))
+
+
+# ----------------------------------------------------------------------------- CLI plumbing (no GPU work)
+def test_cli_arguments_and_experiment_folder(tmp_path):
+    from seeme_amd import cli
+    args = cli.build_parser("train").parse_args(["--cfg", os.path.join(REPO, "configs", "config_mld_egobody.yaml"),
+                                                 "--batch_size", "8", "--nodebug", "--folder", str(tmp_path)])
+    cfg = cli.load_cfg(args, "train")
+    assert cfg.TRAIN.BATCH_SIZE == 8 and cfg.DEBUG is False
+    assert cfg.FOLDER_EXP == os.path.join(str(tmp_path), "mld", "s2_interactee")
+    with pytest.raises(NotImplementedError):
+        cli.load_cfg(cli.build_parser("test").parse_args(["--cfg", args.cfg, "--dir", "x"]), "test")
+
+
+def test_cli_checkpoint_layout_roundtrip(tmp_path):
+    """Lightning layout ({"state_dict": ...}, epoch=<n>.ckpt), newest-epoch resume scan, strict vae.* sub-load."""
+    import torch
+    from seeme_amd import cli
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.vae = torch.nn.Linear(3, 2)
+            self.denoiser = torch.nn.Linear(2, 2)
+            self.optimizer = None
+
+    m = Tiny()
+    m.optimizer = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    d = tmp_path / "exp"
+    for e in (0, 2, 10):
+        cli.save_checkpoint(str(d / "checkpoints" / f"epoch={e}.ckpt"), m, e, 8 * (e + 1))
+    newest = cli.newest_checkpoint(str(d))
+    assert newest.endswith("epoch=10.ckpt")                       # numeric, not lexicographic, order
+    ck = cli.read_checkpoint(newest)
+    assert set(ck["state_dict"]) == set(m.state_dict()) and ck["epoch"] == 10 and ck["global_step"] == 88
+    m2 = Tiny()
+    assert cli.load_pretrained_vae(m2, newest) == 2
+    assert torch.equal(m2.vae.weight, m.vae.weight) and not torch.equal(m2.denoiser.weight, m.denoiser.weight)
+    with pytest.raises(ValueError):
+        cli.newest_checkpoint(str(tmp_path / "missing"))
