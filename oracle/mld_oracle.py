@@ -580,6 +580,57 @@ def mpjpe_mm(pred: Array, gt: Array) -> float:
     return float(np.linalg.norm(pred - gt, axis=-1).mean() * 1000.0)
 
 
+def _quat_matrix(q: Array) -> Array:
+    """transformations.quaternion_matrix (w,x,y,z), the function behind get_root_matrix, compute.py:286-295."""
+    q = np.array(q, dtype=np.float64)
+    n = np.dot(q, q)
+    if n < np.finfo(float).eps * 4.0:
+        return np.identity(3)
+    q *= np.sqrt(2.0 / n)
+    q = np.outer(q, q)
+    return np.array([[1.0 - q[2, 2] - q[3, 3], q[1, 2] - q[3, 0], q[1, 3] + q[2, 0]],
+                     [q[1, 2] + q[3, 0], 1.0 - q[1, 1] - q[3, 3], q[2, 3] - q[1, 0]],
+                     [q[1, 3] - q[2, 0], q[2, 3] + q[1, 0], 1.0 - q[1, 1] - q[2, 2]]])
+
+
+def ego_metrics(jts_pred: Array, jts_ref: Array, quat_pred: Array, quat_ref: Array, lengths, split: str = "test") -> dict:
+    """ComputeMetrics.update + compute, metrics/compute.py:349-580,184-232, as the reference's per-sequence loops:
+    first-frame head alignment (:364-373), align_root (:399), per sequence MPJPE / root error (:470-473), acceleration
+    error (:243-271,474), head-orientation error (:338-346,469) and the split-dependent inclusion rule (:488-517,
+    :567-576).  jts [B,T,24,3] metres; quats [B*T,4] (w,x,y,z)."""
+    B, T = jts_ref.shape[:2]
+    ref = jts_ref - jts_ref[:, 0:1, 15:16, :]
+    pred = jts_pred - jts_pred[:, 0:1, 15:16, :]
+    pel_g, pel_p = ref[:, :, [0]], pred[:, :, [0]]
+    ref, pred = ref - pel_g, pred - pel_p
+    qg, qp = quat_ref.reshape(B, T, 4), quat_pred.reshape(B, T, 4)
+    sums = {k: 0.0 for k in ("MPJPE", "ROOT_ERROR", "ACCL", "HEAD_ORIENTATION_ERROR")}
+    cnt = dict.fromkeys(sums, 0)
+    for b in range(B):
+        L = int(lengths[b])
+        g, p = ref[b, :L].reshape(-1, 24, 3), pred[b, :L].reshape(-1, 24, 3)
+        head = 0.0
+        for t in range(L):
+            head += np.linalg.norm(np.identity(3) - _quat_matrix(qg[b, t]) @ np.linalg.inv(_quat_matrix(qp[b, t])), "fro")
+        head /= L
+        root = np.linalg.norm(pel_g[b, :L].reshape(-1, 3) - pel_p[b, :L].reshape(-1, 3), axis=1).mean() * 1000
+        mp = np.linalg.norm(p - g, axis=-1).mean() * 1000
+        ag, ap = g[:-2] - 2 * g[1:-1] + g[2:], p[:-2] - 2 * p[1:-1] + p[2:]
+        accl = np.mean(np.linalg.norm(ap - ag, axis=2), axis=1)
+        if not np.mean(accl) > 0:
+            continue
+        if split == "test":
+            if head < 0.9 and root < 300:
+                for k, v in (("MPJPE", mp), ("ROOT_ERROR", root), ("ACCL", np.mean(accl) * 1000), ("HEAD_ORIENTATION_ERROR", head)):
+                    sums[k] += v
+                    cnt[k] += 1
+        else:
+            for k, v in (("MPJPE", mp), ("ROOT_ERROR", root)):
+                sums[k] += v
+                cnt[k] += 1
+    return {k: sums[k] / max(cnt[k], 1) for k in sums} | {"count_seq": float(cnt["MPJPE"])}
+
+
 def renorm(x: Array, mean: Array, std: Array) -> Array:
     """EgoBodyDataModule.renorm, mld/data/EgoBody.py:151-157."""
     n = x.shape[-1]

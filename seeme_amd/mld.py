@@ -90,47 +90,82 @@ class MLDLosses:
 
 
 class EgoMetrics:
-    """MPJPE / root error with the reference's alignment (metrics/compute.py:364-399, 470-473):
-    subtract the first-frame head (joint 15) position, then the per-frame pelvis; x1000 (mm);
-    per-sequence means averaged over sequences (:196).  Sums are plain tensors so that the
-    multi-GPU reduction is one small all-reduce (seeme_amd.distributed.reduce_sums)."""
+    """ComputeMetrics of the reference (metrics/compute.py:349-580,184-232) on the device, without its per-sequence
+    `.cpu().numpy()` loops: MPJPE and root error after first-frame head (joint 15) and per-frame pelvis alignment
+    (:364-399,470-473), acceleration error (:243-271,474) and head-orientation error ||I - R_gt R_pred^-1||_F
+    (:338-346,469), x1000 where the reference does; per-sequence means averaged over the sequences the reference
+    counts: on 'test' only those with head error < 0.9, root error < 300 mm and a non-zero acceleration error
+    (:488-517), otherwise those with a non-zero acceleration error (:567-576).  Sums are one device tensor, so
+    the multi-GPU reduction is one small all-reduce (seeme_amd.distributed.reduce_sums)."""
+
+    NAMES = ("MPJPE", "ROOT_ERROR", "ACCL", "HEAD_ORIENTATION_ERROR")
 
     def __init__(self):
         self.reset()
 
     def reset(self):
-        self.mpjpe_sum = 0.0
-        self.root_sum = 0.0
-        self.n_seq = 0
+        self._sums = None            # [4 sums, 4 counts] float64 on the device of the first update
 
     @staticmethod
-    def per_sequence(jts_pred, jts_ref, lengths):
+    def quat_to_rotmat(q):
+        """(w,x,y,z) -> [M,3,3], normalising as transformations.quaternion_matrix does (compute.py:292)."""
+        n = (q * q).sum(-1, keepdim=True)
+        q = q * torch.sqrt(2.0 / n.clamp_min(1e-30))
+        w, x, y, z = q.unbind(-1)
+        R = torch.stack([1 - y * y - z * z, x * y - z * w, x * z + y * w,
+                         x * y + z * w, 1 - x * x - z * z, y * z - x * w,
+                         x * z - y * w, y * z + x * w, 1 - x * x - y * y], dim=-1).reshape(-1, 3, 3)
+        return torch.where((n < 1e-15)[..., None], torch.eye(3, device=q.device, dtype=q.dtype).expand_as(R), R)
+
+    @staticmethod
+    def per_sequence(jts_pred, jts_ref, lengths, quat_pred=None, quat_ref=None):
+        B, T = jts_ref.shape[:2]
+        dev = jts_ref.device
         ref = jts_ref - jts_ref[:, 0:1, 15:16, :]
         pred = jts_pred - jts_pred[:, 0:1, 15:16, :]
         pelvis_ref, pelvis_pred = ref[:, :, [0]], pred[:, :, [0]]
         ref, pred = ref - pelvis_ref, pred - pelvis_pred
-        T = ref.shape[1]
-        lens = torch.as_tensor(lengths, device=ref.device)
-        mask = (torch.arange(T, device=ref.device)[None, :] < lens[:, None]).float()
-        err = (pred - ref).norm(dim=-1).mean(dim=-1)                  # [B,T]
-        mpjpe = (err * mask).sum(1) / lens * 1000.0
-        rerr = (pelvis_pred - pelvis_ref).norm(dim=-1).squeeze(-1)
-        root = (rerr * mask).sum(1) / lens * 1000.0
-        return mpjpe, root
+        lens = torch.as_tensor(lengths, device=dev).reshape(B)
+        frame = torch.arange(T, device=dev)[None, :]
+        mask = (frame < lens[:, None]).to(ref.dtype)
+        out = {}
+        out["MPJPE"] = ((pred - ref).norm(dim=-1).mean(dim=-1) * mask).sum(1) / lens * 1000.0
+        out["ROOT_ERROR"] = ((pelvis_pred - pelvis_ref).norm(dim=-1).squeeze(-1) * mask).sum(1) / lens * 1000.0
+        if T >= 3:   # X[t-1] - 2 X[t] + X[t+1] over the valid frames (compute.py:257-271)
+            acc = lambda x: x[:, :-2] - 2 * x[:, 1:-1] + x[:, 2:]
+            amask = (frame[:, : T - 2] < (lens - 2)[:, None]).to(ref.dtype)
+            an = (acc(pred) - acc(ref)).norm(dim=-1).mean(dim=-1)
+            out["ACCL"] = (an * amask).sum(1) / (lens - 2).clamp_min(1) * 1000.0
+        else:
+            out["ACCL"] = torch.zeros(B, device=dev, dtype=ref.dtype)
+        if quat_pred is not None and quat_ref is not None:
+            Rg = EgoMetrics.quat_to_rotmat(quat_ref.reshape(-1, 4).to(ref.dtype))
+            Rp = EgoMetrics.quat_to_rotmat(quat_pred.reshape(-1, 4).to(ref.dtype))
+            err = (torch.eye(3, device=dev, dtype=ref.dtype) - Rg @ torch.linalg.inv(Rp)).flatten(1).norm(dim=1).reshape(B, T)
+            out["HEAD_ORIENTATION_ERROR"] = (err * mask).sum(1) / lens
+        else:
+            out["HEAD_ORIENTATION_ERROR"] = torch.zeros(B, device=dev, dtype=ref.dtype)
+        return out
 
-    def update(self, jts_pred, jts_ref, lengths):
-        mpjpe, root = self.per_sequence(jts_pred, jts_ref, lengths)
-        self.mpjpe_sum += float(mpjpe.sum())
-        self.root_sum += float(root.sum())
-        self.n_seq += int(mpjpe.numel())
+    def update(self, jts_pred, jts_ref, lengths, quat_pred=None, quat_ref=None, split: str = "test"):
+        m = self.per_sequence(jts_pred, jts_ref, lengths, quat_pred, quat_ref)
+        moving = m["ACCL"] > 0
+        have_q = quat_pred is not None and quat_ref is not None
+        if split == "test" and have_q:
+            keep = moving & (m["HEAD_ORIENTATION_ERROR"] < 0.9) & (m["ROOT_ERROR"] < 300.0)
+            cols = (keep, keep, keep, keep)
+        else:                        # train / val: MPJPE and root error only (compute.py:567-576)
+            none = torch.zeros_like(moving)
+            cols = (moving, moving, none, none) if split != "test" else (moving, moving, moving, none)
+        vals = torch.stack([(m[k] * c).sum() for k, c in zip(self.NAMES, cols)] + [c.sum().to(m["MPJPE"].dtype) for c in cols]).double()
+        self._sums = vals if self._sums is None else self._sums + vals
 
     def sums(self):
-        return torch.tensor([self.mpjpe_sum, self.root_sum, float(self.n_seq)], dtype=torch.float64)
+        return torch.zeros(8, dtype=torch.float64) if self._sums is None else self._sums
 
     def compute(self, sums=None):
-        s = self.sums() if sums is None else sums
-        n = max(float(s[2]), 1.0)
-        return {"MPJPE": float(s[0]) / n, "ROOT_ERROR": float(s[1]) / n}
+        s = (self.sums() if sums is None else sums).detach().double().cpu()
+        return {k: float(s[i]) / max(float(s[4 + i]), 1.0) for i, k in enumerate(self.NAMES)} | {"count_seq": float(s[4])}
 
 
 class SyntheticEgoDataModule:
@@ -447,7 +482,8 @@ class MLD(nn.Module):
             loss = self.losses[split].update(rs_set)
         if split in ("val", "test"):
             rs_set = self.ego_eval(batch)
-            self.EgoMetric.update(rs_set["joints_rst"], rs_set["joints_ref"], rs_set["lengths"])
+            self.EgoMetric.update(rs_set["joints_rst"], rs_set["joints_ref"], rs_set["lengths"],
+                                  rs_set.get("orientation_quat_rst"), rs_set.get("orientation_quat_ref"), split=split)
         if split == "test":
             return rs_set["joints_rst"]
         return loss

@@ -351,8 +351,15 @@ def test_mld_sample_vs_oracle_mpjpe(dev):
     assert mpjpe_between < 1.0          # synthetic SMPL in metres: 1 mm; typical value ~1e-2 mm
     # metric plumbing: MPJPE of prediction vs ground truth equals the oracle's definition after alignment
     from seeme_amd.mld import EgoMetrics
-    m, _ = EgoMetrics.per_sequence(rs["joints_rst"], rs["joints_ref"], rs["lengths"])
-    assert torch.isfinite(m).all()
+    m = EgoMetrics.per_sequence(rs["joints_rst"], rs["joints_ref"], rs["lengths"], rs["orientation_quat_rst"], rs["orientation_quat_ref"])
+    assert all(torch.isfinite(v).all() for v in m.values())
+    want = O.ego_metrics(rs["joints_rst"].double().cpu().numpy(), rs["joints_ref"].double().cpu().numpy(),
+                         rs["orientation_quat_rst"].double().cpu().numpy(), rs["orientation_quat_ref"].double().cpu().numpy(),
+                         rs["lengths"], "val")
+    em = EgoMetrics()
+    em.update(rs["joints_rst"], rs["joints_ref"], rs["lengths"], rs["orientation_quat_rst"], rs["orientation_quat_ref"], split="val")
+    got = em.compute()
+    assert abs(got["MPJPE"] - want["MPJPE"]) < 1e-3 * max(1.0, want["MPJPE"]) and got["count_seq"] == want["count_seq"]
 
 
 def test_autograd_twin_matches_hip(dev):

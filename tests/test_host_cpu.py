@@ -196,3 +196,37 @@ def test_cli_checkpoint_layout_roundtrip(tmp_path):
     assert torch.equal(m2.vae.weight, m.vae.weight) and not torch.equal(m2.denoiser.weight, m.denoiser.weight)
     with pytest.raises(ValueError):
         cli.newest_checkpoint(str(tmp_path / "missing"))
+
+
+# ----------------------------------------------------------------------------- device-side ComputeMetrics
+@pytest.mark.parametrize("split", ["test", "val"])
+def test_ego_metrics_match_reference_loops(split):
+    """Vectorised, device-resident metrics vs the oracle's restatement of the reference's per-sequence numpy loops
+    (metrics/compute.py:349-580): ragged lengths, sequences excluded by the test-split rule, a static sequence."""
+    from seeme_amd.mld import EgoMetrics
+    rng = np.random.default_rng(5)
+    B, T = 6, 20
+    ref = rng.standard_normal((B, T, 24, 3)) * 0.3
+    pred = ref + rng.standard_normal((B, T, 24, 3)) * np.array([0.02, 0.05, 0.02, 0.6, 0.02, 0.02])[:, None, None, None]
+    pred[4] = ref[4]                  # identical: zero acceleration error -> never counted (compute.py:503,567)
+    qg = rng.standard_normal((B * T, 4))
+    qg /= np.linalg.norm(qg, axis=1, keepdims=True)
+    dq = np.concatenate([np.ones((B * T, 1)), 0.05 * rng.standard_normal((B * T, 3))], axis=1)
+    dq[T:2 * T, 1:] *= 30             # sequence 1: large head-orientation error -> excluded on 'test'
+    qp = qg + 0.0
+    qp = np.stack([qg[:, 0] * dq[:, 0] - (qg[:, 1:] * dq[:, 1:]).sum(1),
+                   qg[:, 0] * dq[:, 1] + dq[:, 0] * qg[:, 1] + qg[:, 2] * dq[:, 3] - qg[:, 3] * dq[:, 2],
+                   qg[:, 0] * dq[:, 2] + dq[:, 0] * qg[:, 2] + qg[:, 3] * dq[:, 1] - qg[:, 1] * dq[:, 3],
+                   qg[:, 0] * dq[:, 3] + dq[:, 0] * qg[:, 3] + qg[:, 1] * dq[:, 2] - qg[:, 2] * dq[:, 1]], axis=1)
+    lengths = [20, 20, 13, 20, 20, 7]
+    want = O.ego_metrics(pred, ref, qp, qg, lengths, split)
+    m = EgoMetrics()
+    half = 3
+    for sl in (slice(0, half), slice(half, B)):       # two updates, as over two batches
+        m.update(torch.from_numpy(pred[sl]).float(), torch.from_numpy(ref[sl]).float(), lengths[sl],
+                 torch.from_numpy(qp.reshape(B, T, 4)[sl].reshape(-1, 4)).float(),
+                 torch.from_numpy(qg.reshape(B, T, 4)[sl].reshape(-1, 4)).float(), split=split)
+    got = m.compute()
+    assert got["count_seq"] == want["count_seq"] and 0 < got["count_seq"] < B
+    for k in ("MPJPE", "ROOT_ERROR", "ACCL", "HEAD_ORIENTATION_ERROR"):
+        assert abs(got[k] - want[k]) <= 2e-4 * max(1.0, abs(want[k])), (k, got[k], want[k])
