@@ -98,13 +98,13 @@ class EgoMetrics:
     (:488-517), otherwise those with a non-zero acceleration error (:567-576).  Sums are one device tensor, so
     the multi-GPU reduction is one small all-reduce (seeme_amd.distributed.reduce_sums)."""
 
-    NAMES = ("MPJPE", "ROOT_ERROR", "ACCL", "HEAD_ORIENTATION_ERROR")
+    NAMES = ("MPJPE", "ROOT_ERROR", "ACCL", "HEAD_ORIENTATION_ERROR", "mpjpe_interactee")
 
     def __init__(self):
         self.reset()
 
     def reset(self):
-        self._sums = None            # [4 sums, 4 counts] float64 on the device of the first update
+        self._sums = None            # [5 sums, 5 counts] float64 on the device of the first update
 
     @staticmethod
     def quat_to_rotmat(q):
@@ -147,25 +147,37 @@ class EgoMetrics:
             out["HEAD_ORIENTATION_ERROR"] = torch.zeros(B, device=dev, dtype=ref.dtype)
         return out
 
-    def update(self, jts_pred, jts_ref, lengths, quat_pred=None, quat_ref=None, split: str = "test"):
+    def update(self, jts_pred, jts_ref, lengths, quat_pred=None, quat_ref=None, split: str = "test",
+               jts_int=None, jts_int_gt=None):
         m = self.per_sequence(jts_pred, jts_ref, lengths, quat_pred, quat_ref)
+        every = torch.ones_like(m["MPJPE"], dtype=torch.bool)
+        if jts_int is not None and jts_int_gt is not None:      # POSE_ESTIMATION_TASK: every sequence counts (compute.py:476-481)
+            a, g = jts_int - jts_int[:, :, [0]], jts_int_gt - jts_int_gt[:, :, [0]]
+            T = a.shape[1]
+            lens = torch.as_tensor(lengths, device=a.device).reshape(-1)
+            mask = (torch.arange(T, device=a.device)[None, :] < lens[:, None]).to(a.dtype)
+            m["mpjpe_interactee"] = ((a - g).norm(dim=-1).mean(dim=-1) * mask).sum(1) / lens * 1000.0
+        else:
+            m["mpjpe_interactee"] = torch.zeros_like(m["MPJPE"])
+            every = ~every
         moving = m["ACCL"] > 0
         have_q = quat_pred is not None and quat_ref is not None
         if split == "test" and have_q:
             keep = moving & (m["HEAD_ORIENTATION_ERROR"] < 0.9) & (m["ROOT_ERROR"] < 300.0)
-            cols = (keep, keep, keep, keep)
+            cols = (keep, keep, keep, keep, every)
         else:                        # train / val: MPJPE and root error only (compute.py:567-576)
             none = torch.zeros_like(moving)
-            cols = (moving, moving, none, none) if split != "test" else (moving, moving, moving, none)
+            cols = (moving, moving, none, none, every) if split != "test" else (moving, moving, moving, none, every)
         vals = torch.stack([(m[k] * c).sum() for k, c in zip(self.NAMES, cols)] + [c.sum().to(m["MPJPE"].dtype) for c in cols]).double()
         self._sums = vals if self._sums is None else self._sums + vals
 
     def sums(self):
-        return torch.zeros(8, dtype=torch.float64) if self._sums is None else self._sums
+        return torch.zeros(2 * len(self.NAMES), dtype=torch.float64) if self._sums is None else self._sums
 
     def compute(self, sums=None):
         s = (self.sums() if sums is None else sums).detach().double().cpu()
-        return {k: float(s[i]) / max(float(s[4 + i]), 1.0) for i, k in enumerate(self.NAMES)} | {"count_seq": float(s[4])}
+        n = len(self.NAMES)
+        return {k: float(s[i]) / max(float(s[n + i]), 1.0) for i, k in enumerate(self.NAMES)} | {"count_seq": float(s[n])}
 
 
 class SyntheticEgoDataModule:
@@ -186,7 +198,7 @@ class SyntheticEgoDataModule:
     def renorm(self, features):
         return G.renorm(features, self.mean, self.std)
 
-    def batch(self, B, idx=0, with_scene=False, lengths=None):
+    def batch(self, B, idx=0, with_scene=False, lengths=None, pose_estimation=False):
         g = torch.Generator().manual_seed(self.seed * 7919 + idx)
         T = self.T
         motion = 0.5 * torch.randn(B, T, 2, 72, generator=g)
@@ -199,8 +211,11 @@ class SyntheticEgoDataModule:
         if with_scene:
             out.append((torch.rand(B, self.n_points, 3, generator=g) * 6 - 3).to(dev))
         out.append(length.to(dev))
-        if with_scene:
+        if with_scene and not pose_estimation:
             out.append([])          # img_path / dict_images slot
+        if pose_estimation:         # interactee ground truth: motion [B,T,1,72], transl [B,1,T,3], beta [B,T,1,10] (mld.py:1119-1131)
+            noise = 0.05 * torch.randn(B, T, 72, generator=g)
+            out += [(motion[:, :, 1] + noise).unsqueeze(2).to(dev), transl[:, 1:2].clone().to(dev), beta[:, 1].unsqueeze(2).to(dev)]
         return tuple(out)
 
 
@@ -234,6 +249,7 @@ class MLD(nn.Module):
         self.predict_transl = cfg.TRAIN.ABLATION.PREDICT_TRANSL
         self.data_type = cfg.DATA_TYPE
         self.see_future = cfg.TEST.get("SEE_FUTURE", False)
+        self.pose_estimation_task = cfg.TEST.get("POSE_ESTIMATION_TASK", False)      # mld.py:116
         if self.name_dataset == "egobody":                               # mld.py:122-125
             self.nfeats = 75 if self.predict_transl else 72
         elif self.name_dataset == "gimo":
@@ -414,6 +430,9 @@ class MLD(nn.Module):
     # ------------------------------------------------------------------ evaluation (mld.py:1076-1905, live part)
     @torch.no_grad()
     def ego_eval(self, batch, latents=None, want_vertices=False):
+        int_gt = None
+        if self.pose_estimation_task:       # batch ends with the interactee's ground truth (mld.py:1119-1131)
+            batch, int_gt = tuple(batch[:-3]), tuple(t.float() for t in batch[-3:])
         if "scene" in self.condition:
             feats_ref, transl, beta, utils_, scene, length = batch[:6]
             scene_tok = self._scene_token(scene)
@@ -454,11 +473,18 @@ class MLD(nn.Module):
         joints_ref, joints_rst = (out_ref[0], out_rst[0]) if want_vertices else (out_ref, out_rst)
         f_int_r = self.renorm(self._wearer_features(feats_ref[:, :min_len], transl[:, :, :min_len], 1))
         joints_int = self._feats_to_joints(f_int_r, beta[:, 1, :min_len])
+        joints_int_gt = None
+        if int_gt is not None:              # mld.py:1843-1866: SMPL joints of the interactee's ground-truth motion
+            g_motion, g_transl, _g_beta = int_gt
+            f_gt = g_motion[:, :min_len, 0]
+            if self.predict_transl:
+                f_gt = torch.cat([f_gt, g_transl[:, 0, :min_len]], dim=-1)
+            joints_int_gt = self._feats_to_joints(self.renorm(f_gt[..., : self.nfeats].contiguous()), beta[:, 1, :min_len])
         quat = (lambda f: G.aa_to_quat(f[:, :, :3].reshape(-1, 3).contiguous())) if self.data_type == "angle" else (lambda f: None)
         rs = {"m_ref": f_ref, "m_rst": f_rst, "joints_ref": joints_ref, "joints_rst": joints_rst,
               "orientation_quat_rst": quat(f_rst), "orientation_quat_ref": quat(f_ref),
               "root_interactee": joints_int[:, :, 0], "joints_interactee": joints_int,
-              "orientation_quat_int": quat(f_int_r), "joints_interactee_gt": None, "lengths": lengths,
+              "orientation_quat_int": quat(f_int_r), "joints_interactee_gt": joints_int_gt, "lengths": lengths,
               "list_names": {}, "lat_t": z}
         if want_vertices:
             rs["vertices_ref"], rs["vertices_rst"] = out_ref[1], out_rst[1]
@@ -483,7 +509,8 @@ class MLD(nn.Module):
         if split in ("val", "test"):
             rs_set = self.ego_eval(batch)
             self.EgoMetric.update(rs_set["joints_rst"], rs_set["joints_ref"], rs_set["lengths"],
-                                  rs_set.get("orientation_quat_rst"), rs_set.get("orientation_quat_ref"), split=split)
+                                  rs_set.get("orientation_quat_rst"), rs_set.get("orientation_quat_ref"), split=split,
+                                  jts_int=rs_set.get("joints_interactee"), jts_int_gt=rs_set.get("joints_interactee_gt"))
         if split == "test":
             return rs_set["joints_rst"]
         return loss

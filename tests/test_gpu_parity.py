@@ -558,3 +558,33 @@ def test_cli_train_resume_and_test(dev, tmp_path):
     out = cli.test_main(["--cfg", cfgp, "--batch_size", "4", "--folder", str(tmp_path), "--frames", "24", "--test_batches", "2",
                          "--checkpoint", os.path.join(r2["checkpoints"], "epoch=2.ckpt")])
     assert np.isfinite(out["Metrics/MPJPE/mean"]) and os.path.exists(out["file"])
+
+
+def test_ego_eval_variants(dev):
+    """The config-toggled variants of ego_eval on the HIP path: POSE_ESTIMATION_TASK (interactee ground truth at the
+    end of the batch -> joints_interactee_gt and the mpjpe_interactee metric, mld.py:1119-1131,1843-1866), SEE_FUTURE
+    (half-length decode, :1357-1358) and classifier-free guidance with a scene token (:1144-1158)."""
+    from seeme_amd.config import parse_config
+    from seeme_amd.mld import MLD, SyntheticEgoDataModule
+    from seeme_amd.smpl import SMPL
+    cfg = parse_config(os.path.join(REPO, "configs", "config_mld_scene.yaml"))
+    cfg.TEST.POSE_ESTIMATION_TASK = True
+    cfg.model.guidance_scale = 2.0
+    dm = SyntheticEgoDataModule(nfeats=75, T=24, n_points=512, device=dev)
+    model = MLD(cfg, dm, smpl_model=SMPL.synthetic(1234)).to(dev).eval()
+    batch = dm.batch(3, idx=1, with_scene=True, pose_estimation=True, lengths=[24, 17, 24])
+    rs = model.ego_eval(batch)
+    assert rs["joints_interactee_gt"].shape == rs["joints_interactee"].shape == (3, 24, 24, 3)
+    model.EgoMetric.reset()
+    model.test_step(batch)
+    got = model.EgoMetric.compute()
+    want = float(np.mean([np.linalg.norm((rs["joints_interactee"][b, :L] - rs["joints_interactee"][b, :L, [0]]
+                                          - rs["joints_interactee_gt"][b, :L] + rs["joints_interactee_gt"][b, :L, [0]]).cpu().numpy(),
+                                         axis=-1).mean() * 1000 for b, L in enumerate([24, 17, 24])]))
+    assert want > 0 and abs(got["mpjpe_interactee"] - want) < 1e-3 * want
+    # SEE_FUTURE: the decoded motion covers half of each length
+    cfg2 = parse_config(os.path.join(REPO, "configs", "config_mld_egobody.yaml"))
+    cfg2.TEST.SEE_FUTURE = True
+    m2 = MLD(cfg2, dm, smpl_model=SMPL.synthetic(1234)).to(dev).eval()
+    rs2 = m2.ego_eval(dm.batch(2, idx=2))
+    assert rs2["m_rst"].shape[1] == 12 and rs2["lengths"] == [12, 12] and torch.isfinite(rs2["joints_rst"]).all()
