@@ -198,9 +198,28 @@ typedef struct {
     const float* noise;    /* optional [steps,B,256] step noise (eta>0 / DDPM), NULL otherwise */
     float* out;            /* [B,256] */
     const float* catab;    /* N == 1: [B or 2B, R, 5, 256] from seeme_denoiser_ca_tables (R = steps, or 1 with trow_per_sample) */
+    float* save;           /* training forward only (steps == 1, no CFG, unfolded fp32 image, query GEMV kept): [B, SEEME_DEN_SAVE_FLOATS]
+                            * intermediates for seeme_denoiser_backward (seeme_amd/csrc/den_train.h); NULL otherwise */
+    int force_query;       /* 1: keep the ca_block query / proj_out GEMVs even for one condition token (differentiable path) */
 } SeemeSampleArgs;
 
 int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeSampleArgs* a, void* stream);
+
+/* ---- stage-2 training (MLD._diffusion_process, mld.py:582-631, and the backward of MldDenoiser.forward) ----
+ * Forward = seeme_denoiser_sample with steps 1, SCHED_NONE, per-sample rows, force_query 1 and `save` set, on the
+ * unfolded fp32 image.  seeme_den_train_pack refreshes that image, its transposed twin and the vector array from the
+ * parameter tensors (mats: [5][10] device pointers in den_layout.h order, NULL where a layer has no skip linear).
+ * seeme_denoiser_backward walks the chain in reverse (one workgroup per sample) and writes, per sample, x and dy of
+ * every linear + LayerNorm parameter terms + d(first layer input) into gout [B, DB_TOTAL] (seeme_amd/csrc/den_train.h),
+ * and the gradients of the tables into dctab [B,N,SEEME_CROW] / dttab [B,SEEME_TROW].  The batch reductions
+ * (dW = sum_b dy_b x_b^T) are left to the host.  seeme_den_train_layout: [5][10] offsets of the transposed image,
+ * its size, floats of `save` per sample, floats of `gout` per sample, floats per layer block of `gout`. */
+int seeme_den_train_layout(int64_t* out, int cap);
+int seeme_den_train_pack(const float* const* mats, float* img_f, float* img_b, const float* const* vec_src,
+                         const int* vec_n, const int64_t* vec_dst, int n_vec, float* vp, void* stream);
+int seeme_denoiser_backward(const SeemeDenoiserWeights* w, const void* img_bwd, int B, int N, const float* save,
+                            const float* ctab, const float* ttab, const int32_t* trow, const float* dout,
+                            float* gout, float* dctab, float* dttab, void* stream);
 
 /* Offsets of the packed weight image (30 per layer x 5, then pe0, fnw, fnb, wg_total, vp_total). */
 int seeme_den_layout(int ff_sa, int ff, int64_t* out, int cap);

@@ -83,7 +83,7 @@ class DenoiserWeights(C.Structure):
 class SampleArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("N", C.c_int), ("steps", C.c_int), ("sched", C.c_int), ("cfg", C.c_int),
                 ("guidance_scale", C.c_float), ("latents", fp), ("ctab", fp), ("ttab", fp), ("trow", fp),
-                ("trow_per_sample", C.c_int), ("coef", fp), ("noise", fp), ("out", fp), ("catab", fp)]
+                ("trow_per_sample", C.c_int), ("coef", fp), ("noise", fp), ("out", fp), ("catab", fp), ("save", fp), ("force_query", C.c_int)]
 
 
 class SmplModel(C.Structure):
@@ -116,6 +116,9 @@ _SIGNATURES = {
     "seeme_denoiser_cond_tables": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
     "seeme_denoiser_ca_tables": (C.c_int, [C.POINTER(DenoiserWeights), fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
     "seeme_denoiser_sample": (C.c_int, [C.POINTER(DenoiserWeights), C.POINTER(SampleArgs), fp]),
+    "seeme_den_train_layout": (C.c_int, [C.POINTER(C.c_int64), C.c_int]),
+    "seeme_den_train_pack": (C.c_int, [fp, fp, fp, fp, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.c_int, fp, fp]),
+    "seeme_denoiser_backward": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp]),
     "seeme_den_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "seeme_geometry": (C.c_int, [C.c_int, fp, fp, C.c_int, fp]),
     "seeme_renorm": (C.c_int, [fp, fp, fp, fp, C.c_long, C.c_int, fp]),

@@ -16,6 +16,7 @@
 #include "api_util.hpp"
 #include "den_layout.h"
 #include "lds_ring.hpp"
+#include "den_train.h"
 #include <utility>
 
 #define DEN_THREADS 512
@@ -48,9 +49,19 @@ struct Ring { u32x4 r[DEN_R][DEN_CH]; };
 
 // ------------------------------------------------------------------ the static weight-stream program
 // GEMV ids = index of the matrix offset inside DenLayerOff (den_layout.h).
-enum { G_SKIP = 0, G_INP, G_OUTP, G_L1, G_L2, G_CAQ, G_CAO, G_F1, G_F2, G_FO, G_NUM };
-constexpr int den_gK(int g) { constexpr int k[G_NUM] = {512, 256, 256, 256, FF_SA, 256, 256, 256, FF_D, 256}; return k[g]; }
-constexpr int den_gN(int g) { constexpr int n[G_NUM] = {256, 768, 256, FF_SA, 256, 256, 256, FF_D, 256, 256}; return n[g]; }
+enum { G_SKIP = 0, G_INP, G_OUTP, G_L1, G_L2, G_CAQ, G_CAO, G_F1, G_F2, G_FO, G_NUM,
+       // transposed GEMVs of the backward chain (dX = W^T dY): K = out-features, N = in-features of the forward matrix
+       GB_FO = G_NUM, GB_F2, GB_F1, GB_CAO, GB_CAQ, GB_L2, GB_L1, GB_OUTP, GB_INP, GB_SKIP, G_ALL };
+constexpr int den_gK(int g) {
+    constexpr int k[G_ALL] = {512, 256, 256, 256, FF_SA, 256, 256, 256, FF_D, 256,
+                              256, 256, FF_D, 256, 256, 256, FF_SA, 256, 768, 256};
+    return k[g];
+}
+constexpr int den_gN(int g) {
+    constexpr int n[G_ALL] = {256, 768, 256, FF_SA, 256, 256, 256, FF_D, 256, 256,
+                              256, FF_D, 256, 256, 256, FF_SA, 256, 256, 256, 512};
+    return n[g];
+}
 
 // GEMV work split over the 512 threads.  A PyTorch [N,K] matrix is stored as [K/KV][N] 16-B vectors.  An
 // "item" = (k-slice ks, output pair n0 / n0 + N/2); thread tid owns items tid, tid+512, ...  Both outputs of
@@ -307,6 +318,24 @@ __device__ __forceinline__ void refill(Ring& ring, int tid, __amdgpu_buffer_rsrc
     if constexpr (TGT < 0) issue_mat<WT, G_SKIP, TGT + Prog<WT, V>::TS>(ring.r[((TGT % DEN_R) + DEN_R) % DEN_R], tid, rsrc, mo.m[G_SKIP]);
     else issue_rel<WT, V, TGT>(ring, tid, rsrc, mo, nskip);
 }
+// vector-ALU consume of chunk C of GEMV G: accumulate, and publish the item's partial sums at its last chunk
+template <typename WT, int MS, int G, int C>
+__device__ __forceinline__ void consume_chunk_valu(const u32x4 (&slot)[DEN_CH], int tid, const float* __restrict__ xf,
+                                                   float* __restrict__ part, Acc<WT, MS, G>& acc) {
+    typedef GS<WT, G> S;
+    constexpr int it = C / S::CPI, cc = C % S::CPI;
+    int ks, n0;
+    S::item(tid, it, ks, n0);
+    if constexpr (cc == 0) acc.zero();
+    consume<WT, MS>(slot, xf, XB_LD, (ks * S::NQ + cc * 4) * WT::KV, acc.v);
+    if constexpr (cc == S::CPI - 1) {
+#pragma unroll
+        for (int s = 0; s < MS; ++s)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                part[(ks * MS + s) * S::N + n0 + j * S::G0] = (acc.v[s][j][0].x + acc.v[s][j][0].y) + (acc.v[s][j][1].x + acc.v[s][j][1].y);
+    }
+}
 template <typename WT, int V, int MS, int G, int REL0, int NC, int BURST, int C>
 __device__ __forceinline__ void gemv_chunk(Ring& ring, int tid, __amdgpu_buffer_rsrc_t rsrc, const MatOffs& mo, bool nskip,
                                            const XIn& x, float* __restrict__ part, Acc<WT, MS, G>& acc) {
@@ -341,18 +370,7 @@ __device__ __forceinline__ void gemv_chunk(Ring& ring, int tid, __amdgpu_buffer_
             }
         }
     } else if constexpr (C < S::TOT) {
-        constexpr int it = C / S::CPI, cc = C % S::CPI;
-        int ks, n0;
-        S::item(tid, it, ks, n0);
-        if constexpr (cc == 0) acc.zero();
-        consume<WT, MS>(ring.r[SLOT], x.xf, XB_LD, (ks * S::NQ + cc * 4) * WT::KV, acc.v);
-        if constexpr (cc == S::CPI - 1) {
-#pragma unroll
-            for (int s = 0; s < MS; ++s)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    part[(ks * MS + s) * S::N + n0 + j * S::G0] = (acc.v[s][j][0].x + acc.v[s][j][0].y) + (acc.v[s][j][1].x + acc.v[s][j][1].y);
-        }
+        consume_chunk_valu<WT, MS, G, C>(ring.r[SLOT], tid, x.xf, part, acc);
     }
     acc.pin();
     if constexpr (C < NC - BURST) {
@@ -443,6 +461,16 @@ __device__ __forceinline__ float4 wave_ln(float4 v, const float* __restrict__ w,
     const float rs = fast_rsq(wave_sum(f4_dot(c, c)) * (1.f / 256.f) + 1e-5f);
     const float4 wv = ld4(w + 4 * lane), bv = ld4(b + 4 * lane);
     return make_float4(c.x * rs * wv.x + bv.x, c.y * rs * wv.y + bv.y, c.z * rs * wv.z + bv.z, c.w * rs * wv.w + bv.w);
+}
+// same, also returning the normalised vector and the reciprocal standard deviation (saved for the backward pass)
+__device__ __forceinline__ float4 wave_ln_stats(float4 v, const float* __restrict__ w, const float* __restrict__ b, int lane,
+                                                float4& xhat, float& rs) {
+    const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+    const float4 c = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+    rs = fast_rsq(wave_sum(f4_dot(c, c)) * (1.f / 256.f) + 1e-5f);
+    xhat = f4_scale(c, rs);
+    const float4 wv = ld4(w + 4 * lane), bv = ld4(b + 4 * lane);
+    return make_float4(xhat.x * wv.x + bv.x, xhat.y * wv.y + bv.y, xhat.z * wv.z + bv.z, xhat.w * wv.w + bv.w);
 }
 __device__ __forceinline__ float4 f4_silu(float4 v) { return make_float4(fast_silu(v.x), fast_silu(v.y), fast_silu(v.z), fast_silu(v.w)); }
 __device__ __forceinline__ float4 f4_adaln(float4 h, float4 scl, float4 shf) {
@@ -601,6 +629,10 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
 
     const float sa_scale = 1.f / sqrtf((float)(256 / H));   // (once per kernel)
     if (epi) __builtin_amdgcn_s_setprio(3);      // the chain of dependent epilogues is the critical path
+    // training forward: every intermediate the backward kernel needs goes to A.save (den_train.h); only the unfolded,
+    // query-GEMV variant is differentiable (the folds merge parameters), and only it carries the stores
+    constexpr bool SAVE = CAQ && !FOLD && MS == 1;
+    float* const sv0 = (SAVE && A.save != nullptr && epi) ? A.save + (size_t)den_lat_index<MS>(A, b, es) * DT_TOTAL : nullptr;
     float* const keep = KEEP + es * 768 + 4 * lane;   // [0] latent, [256] layer-0 output, [512] layer-1 output
     const int bl = den_lat_index<MS>(A, b, es);          // this epilogue wave's row of latents / noise / out
     float4 xr = ld4(A.latents + (size_t)bl * 256 + 4 * lane);
@@ -649,6 +681,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             const float* TTS = VP + VP_LAYER;                // time-token K|V (512) + AdaLN rows (1024)
             const float* CTS = TTS + STG_TT;                 // [MS][N][1024] condition K|V (sa 512 | ca 512)
             const float* CT = CTS + es * N * 1024;
+            float* const sv = sv0 ? sv0 + l * DT_LAYER : nullptr;
             const float* CA_ADD = CTS + MS * N * 1024 + es * 256;   // (one condition token) tabulated ca_block term
             // offsets inside VP (relative to skip_b)
             const float* v_skip_b = VP;
@@ -683,6 +716,10 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                 const float4 q = f4_add(gemv_out<WT, MS, G_INP>(PART, es, 0, lane), ld4(v_in_b + 4 * lane));
                 const float4 k0 = f4_add(gemv_out<WT, MS, G_INP>(PART, es, 256, lane), ld4(v_in_b + 256 + 4 * lane));
                 const float4 v0 = f4_add(gemv_out<WT, MS, G_INP>(PART, es, 512, lane), ld4(v_in_b + 512 + 4 * lane));
+                if (SAVE && sv) {
+                    st4(sv + DT_X + 4 * lane, xr);
+                    st4(sv + DT_QKV + 4 * lane, q); st4(sv + DT_QKV + 256 + 4 * lane, k0); st4(sv + DT_QKV + 512 + 4 * lane, v0);
+                }
                 float sc[DEN_MAXTOK];
                 sc[0] = seg_reduce<false>(f4_dot(q, k0), seg) * sa_scale;
                 float mx = sc[0];
@@ -701,6 +738,15 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                 for (int j = 0; j < DEN_MAXTOK - 2; ++j)
                     if (j < N) att = f4_fma(sc[1 + j] * inv, ld4(CT + j * 1024 + 256 + 4 * lane), att);
                 att = f4_fma(et * inv, ld4(TTS + 256 + 4 * lane), att);
+                if (SAVE && sv) {
+                    st4(sv + DT_A + 4 * lane, att);
+                    if (lane == 0) {
+                        sv[DT_P] = e0 * inv;
+#pragma unroll
+                        for (int j = 0; j < DEN_MAXTOK - 2; ++j) if (j < N) sv[DT_P + 1 + j] = sc[1 + j] * inv;
+                        sv[DT_P + 1 + N] = et * inv;
+                    }
+                }
                 if constexpr (FOLD) {   // the "values" already carry out_proj: residual + norm1 right here
                     xr = wave_ln(f4_add(xr, att), v_n1w, v_n1b, lane);
                     put_x<WT, MS>(XB, es, 0, lane, xr);
@@ -714,7 +760,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                 gemv_stream<WT, V, MS, G_OUTP, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
                 if (epi) {
                     const float4 v = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_out_b + 4 * lane)));
-                    xr = wave_ln(v, v_n1w, v_n1b, lane);
+                    float4 xh; float rs;
+                    xr = wave_ln_stats(v, v_n1w, v_n1b, lane, xh, rs);
+                    if (SAVE && sv) { st4(sv + DT_XH1 + 4 * lane, xh); if (lane == 0) sv[DT_RS + 0] = rs; }
                     put_x<WT, MS>(XB, es, 0, lane, xr);
                 }
                 __syncthreads(); DEN_DBG(0);
@@ -725,7 +773,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
 #pragma unroll
                 for (int j = 0; j < FF_SA / 256; ++j) {
                     const float4 h = f4_add(gemv_out<WT, MS, G_L1>(PART, es, 256 * j, lane), ld4(v_l1b + 256 * j + 4 * lane));
-                    put_x<WT, MS>(XB, es, 256 * j, lane, make_float4(fmaxf(h.x, 0.f), fmaxf(h.y, 0.f), fmaxf(h.z, 0.f), fmaxf(h.w, 0.f)));
+                    const float4 hr = make_float4(fmaxf(h.x, 0.f), fmaxf(h.y, 0.f), fmaxf(h.z, 0.f), fmaxf(h.w, 0.f));
+                    if (SAVE && sv) st4(sv + DT_H + 256 * j + 4 * lane, hr);
+                    put_x<WT, MS>(XB, es, 256 * j, lane, hr);
                 }
             }
             __syncthreads(); DEN_DBG(0);
@@ -733,9 +783,16 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             gemv_stream<WT, V, MS, G_L2, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
             if (epi) {
                 const float4 v = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_l2b + 4 * lane)));
-                xr = wave_ln(v, v_n2w, v_n2b, lane);
+                float4 xh2; float rs2;
+                xr = wave_ln_stats(v, v_n2w, v_n2b, lane, xh2, rs2);
                 if constexpr (CAQ) {
-                    put_x<WT, MS>(XB, es, 0, lane, wave_ln(xr, v_cnw, v_cnb, lane));          // ca_block.norm -> query input
+                    float4 xhc; float rsc;
+                    const float4 qn = wave_ln_stats(xr, v_cnw, v_cnb, lane, xhc, rsc);       // ca_block.norm -> query input
+                    if (SAVE && sv) {
+                        st4(sv + DT_XH2 + 4 * lane, xh2); st4(sv + DT_XHC + 4 * lane, xhc);
+                        if (lane == 0) { sv[DT_RS + 1] = rs2; sv[DT_RS + 2] = rsc; }
+                    }
+                    put_x<WT, MS>(XB, es, 0, lane, qn);
                 } else {
                     // ONE condition token: x + Stylization(v) with a term that does not depend on x (table)
                     xr = f4_add(xr, ld4(CA_ADD + 4 * lane));
@@ -774,9 +831,15 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                         if (j < N) {
                             const float4 kc = make_float4(kr[j].x * rks.x, kr[j].y * rks.y, kr[j].z * rks.z, kr[j].w * rks.w);
                             const float dot = seg_reduce<false>(f4_dot(qc, kc), seg);                      // q . k_n per head
+                            if (SAVE && sv && lane == 0) sv[DT_RS + 8 + j] = dot;
                             y = f4_fma(dot, ld4(CT + j * 1024 + 768 + 4 * lane), y);                       // (q k^T) v  (:236-237)
                         }
-                    const float4 hh = f4_adaln(wave_ln(y, v_csnw, v_csnb, lane), ld4(TTS + 512 + 4 * lane), ld4(TTS + 768 + 4 * lane));
+                    float4 xhy; float rsy;
+                    const float4 hh = f4_adaln(wave_ln_stats(y, v_csnw, v_csnb, lane, xhy, rsy), ld4(TTS + 512 + 4 * lane), ld4(TTS + 768 + 4 * lane));
+                    if (SAVE && sv) {
+                        st4(sv + DT_QC + 4 * lane, qc); st4(sv + DT_XHY + 4 * lane, xhy); st4(sv + DT_U + 4 * lane, hh);
+                        if (lane == 0) sv[DT_RS + 3] = rsy;
+                    }
                     put_x<WT, MS>(XB, es, 0, lane, f4_silu(hh));
                 }
                 __syncthreads(); DEN_DBG(0);
@@ -784,6 +847,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                 gemv_stream<WT, V, MS, G_CAO, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
                 if (epi) {
                     xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_cao_b + 4 * lane)));
+                    if (SAVE && sv) st4(sv + DT_X3 + 4 * lane, xr);
                     put_x<WT, MS>(XB, es, 0, lane, xr);
                 }
                 __syncthreads(); DEN_DBG(0);
@@ -796,6 +860,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                                                 A.trow_per_sample ? 0 : (ln == 0 ? step_next : step), ca_R);
             if (epi && lane < FF_D / 4) {
                 const float4 g = f4_add(gemv_out<WT, MS, G_F1>(PART, es, 0, lane), ld4(v_f1b + 4 * lane));
+                if (SAVE && sv) st4(sv + DT_Z1 + 4 * lane, g);
                 put_x<WT, MS>(XB, es, 0, lane, make_float4(fast_gelu(g.x), fast_gelu(g.y), fast_gelu(g.z), fast_gelu(g.w)));
             }
             __syncthreads(); DEN_DBG(0);
@@ -805,7 +870,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                                                 A.trow_per_sample ? 0 : (ln == 0 ? step_next : step), ca_R);
             if (epi) {
                 const float4 y2 = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_f2b + 4 * lane));
-                const float4 hh = f4_adaln(wave_ln(y2, v_fsnw, v_fsnb, lane), ld4(TTS + 1024 + 4 * lane), ld4(TTS + 1280 + 4 * lane));
+                float4 xhy2; float rsy2;
+                const float4 hh = f4_adaln(wave_ln_stats(y2, v_fsnw, v_fsnb, lane, xhy2, rsy2), ld4(TTS + 1024 + 4 * lane), ld4(TTS + 1280 + 4 * lane));
+                if (SAVE && sv) { st4(sv + DT_XHY2 + 4 * lane, xhy2); st4(sv + DT_U2 + 4 * lane, hh); if (lane == 0) sv[DT_RS + 4] = rsy2; }
                 put_x<WT, MS>(XB, es, 0, lane, f4_silu(hh));
             }
             __syncthreads(); DEN_DBG(0);
@@ -815,6 +882,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             if (l + 1 < SEEME_DEN_NL) {
                 if (epi) {
                     xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_fo_b + 4 * lane)));
+                    if (SAVE && sv) st4(sv + DT_X4 + 4 * lane, xr);
                     if (l < 2) st4(keep + 256 + 256 * l, xr);                                   // xs.append(x) (cross_attention.py:70-72)
                     put_x<WT, MS>(XB, es, 0, lane, xr);
                     if (nskip) put_x<WT, MS>(XB, es, 256, lane, ld4(keep + (ln == 3 ? 512 : 256)));   // xs.pop(): layer 3 <- layer 1, layer 4 <- layer 0
@@ -825,7 +893,13 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                 float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (epi) {
                     xr = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_fo_b + 4 * lane)));
-                    e = wave_ln(xr, CONSTV + 256, CONSTV + 512, lane);
+                    float4 xhf; float rsf;
+                    e = wave_ln_stats(xr, CONSTV + 256, CONSTV + 512, lane, xhf, rsf);
+                    if (SAVE && sv) {
+                        st4(sv + DT_X4 + 4 * lane, xr);
+                        st4(sv0 + DT_FIN + 4 * lane, xhf);
+                        if (lane == 0) sv0[DT_FIN + 256] = rsf;
+                    }
                     if (MS == 2) st4(PART + es * 256 + 4 * lane, e);
                 }
                 if (MS == 2) {   // classifier-free guidance (mld.py:488-492), uncond (sample 0) first
@@ -889,7 +963,7 @@ static int launch_den(const DenKArgs& ka, hipStream_t st) {
 }
 template <typename WT, int MS>
 static int launch_den_ms(const DenKArgs& ka, bool fold, hipStream_t st) {
-    const bool caq = ka.s.N > 1;
+    const bool caq = ka.s.N > 1 || ka.s.force_query;
     if (caq) return fold ? launch_den<WT, MS, V_CAQ | V_FOLD>(ka, st) : launch_den<WT, MS, V_CAQ>(ka, st);
     return fold ? launch_den<WT, MS, V_FOLD>(ka, st) : launch_den<WT, MS, 0>(ka, st);
 }
@@ -909,6 +983,8 @@ extern "C" int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeS
     if (w->layout == nullptr) return seeme_fail("denoiser_sample: layout table missing");
     if (a->sched == SEEME_SCHED_NONE && a->steps != 1) return seeme_fail("denoiser_sample: SCHED_NONE needs steps == 1");
     if (a->steps < 1) return seeme_fail("denoiser_sample: steps must be >= 1");
+    if (a->save != nullptr && (a->steps != 1 || a->cfg || w->sa_fold || w->wdtype != 0 || !(a->N > 1 || a->force_query) || !a->trow_per_sample))
+        return seeme_fail("denoiser_sample: save needs one step, no CFG, the unfolded fp32 image, the query GEMV and per-sample rows");
     DenKArgs ka;
     ka.wg = w->wg; ka.vp = w->vp; ka.lay = seeme_make_den_layout(FF_SA, FF_D);
     ka.wg_bytes = (int)(ka.lay.wg_total * (w->wdtype == 0 ? 4 : 2));
@@ -916,7 +992,7 @@ extern "C" int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeS
     hipStream_t st = (hipStream_t)stream;
     const bool fold = w->sa_fold != 0;
     if (fold && w->nhead != 1) return seeme_fail("denoiser_sample: sa_fold needs nhead == 1");
-    if (a->N == 1 && a->catab == nullptr) return seeme_fail("denoiser_sample: N == 1 needs the ca table (seeme_denoiser_ca_tables)");
+    if (a->N == 1 && a->catab == nullptr && !a->force_query) return seeme_fail("denoiser_sample: N == 1 needs the ca table (seeme_denoiser_ca_tables)");
     if (w->wdtype == 0) return launch_den_wt<WF32>(ka, fold, st);
     if (w->wdtype == 1) return launch_den_wt<WBF16>(ka, fold, st);
     if (w->wdtype == 2) return launch_den_wt<WF16>(ka, fold, st);
@@ -1018,3 +1094,5 @@ extern "C" int seeme_debug_den_times(unsigned long long* host, int n) {
     return 0;
 }
 #endif
+
+#include "den_train.inc.hip"

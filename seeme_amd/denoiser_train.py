@@ -1,0 +1,222 @@
+"""Stage-2 training of the denoiser on the HIP path: forward + hand-written backward of the token-0 chain.
+
+``MLD._diffusion_process`` (mld/models/modeltype/mld.py:582-631) calls :func:`denoiser_forward_hip_train` when the
+denoiser has one attention head (all shipped ``config_mld_*.yaml``); other shapes keep the PyTorch autograd twin
+(``denoiser_autograd.py``).  Division of labour:
+
+* the persistent kernels do what is a dependent chain per sample: the denoiser forward (the sampling kernel, one step,
+  per-sample timesteps, unfolded fp32 weights, intermediates saved) and its backward (``k_den_bwd``,
+  ``seeme_amd/csrc/den_train.inc.hip``), one workgroup per sample;
+* what is a reduction over the batch is a handful of batched GEMMs / sums on the buffers the backward kernel writes
+  (x and dy of every linear, LayerNorm parameter terms): ``dW = sum_b dy_b x_b^T``;
+* the condition / time tables (K|V of the condition and time tokens, linear-attention keys | values, AdaLN rows,
+  timestep embedding MLP) are built with ~10 differentiable torch ops, and autograd carries the table gradients
+  returned by the kernel back into their parameters (``in_proj`` rows 256.. are shared between the chain and the
+  tables; autograd adds the two contributions).
+
+The weight images (forward and transposed layouts) are refreshed from the parameter tensors by one pack kernel per step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from .mld_denoiser import _LAYER_FIELDS, timestep_features
+
+# (forward matrix id in DenLayerOff order, offset of X / dY in the backward buffer, in-features K, out-features N)
+_MATS = ("skip", "inp", "outp", "l1", "l2", "caq", "cao", "f1", "f2", "fo")
+
+
+def _train_layout():
+    n = 54
+    buf = (C.c_int64 * n)()
+    L.check(L.lib().seeme_den_train_layout(buf, n), "seeme_den_train_layout")
+    v = list(buf)
+    return {"bwd_total": v[50], "DT_TOTAL": v[51], "DB_TOTAL": v[52], "DB_LAYER": v[53]}
+
+
+# offsets inside one layer block of the backward buffer (seeme_amd/csrc/den_train.h)
+_DB = dict(X_INP=0, X_OUTP=256, X_L1=512, X_L2=768, X_CAQ=1792, X_CAO=2048, X_F1=2304, X_F2=2560, X_FO=2688, X_SKIP=2944,
+           Y_INP=3456, Y_OUTP=4224, Y_L1=4480, Y_L2=5504, Y_CAQ=5760, Y_CAO=6016, Y_F1=6272, Y_F2=6400, Y_FO=6656,
+           Y_SKIP=6912, LN=7168)
+# name -> (X offset, K, dY offset, N)
+_LIN = {"inp": ("X_INP", 256, "Y_INP", 768), "outp": ("X_OUTP", 256, "Y_OUTP", 256), "l1": ("X_L1", 256, "Y_L1", 1024),
+        "l2": ("X_L2", 1024, "Y_L2", 256), "caq": ("X_CAQ", 256, "Y_CAQ", 256), "cao": ("X_CAO", 256, "Y_CAO", 256),
+        "f1": ("X_F1", 256, "Y_F1", 128), "f2": ("X_F2", 128, "Y_F2", 256), "fo": ("X_FO", 256, "Y_FO", 256),
+        "skip": ("X_SKIP", 512, "Y_SKIP", 256)}
+
+
+def _layer_params(den, l):
+    """The chain's parameters of layer l, keyed like den_layout.h."""
+    blk = den.encoder.blocks()[l]
+    sa, ca, ffn = blk.sa_block, blk.ca_block, blk.ffn
+    p = {"inp": (sa.self_attn.in_proj_weight, sa.self_attn.in_proj_bias, "in_b"),
+         "outp": (sa.self_attn.out_proj.weight, sa.self_attn.out_proj.bias, "out_b"),
+         "l1": (sa.linear1.weight, sa.linear1.bias, "l1b"), "l2": (sa.linear2.weight, sa.linear2.bias, "l2b"),
+         "caq": (ca.query.weight, ca.query.bias, "caq_b"),
+         "cao": (ca.proj_out.out_layers[2].weight, ca.proj_out.out_layers[2].bias, "cao_b"),
+         "f1": (ffn.linear1.weight, ffn.linear1.bias, "f1b"), "f2": (ffn.linear2.weight, ffn.linear2.bias, "f2b"),
+         "fo": (ffn.proj_out.out_layers[2].weight, ffn.proj_out.out_layers[2].bias, "fo_b")}
+    if l >= 3:
+        lin = den.encoder.linear_blocks[l - 3]
+        p["skip"] = (lin.weight, lin.bias, "skip_b")
+    norms = [(sa.norm1, "n1w", "n1b"), (sa.norm2, "n2w", "n2b"), (ca.norm, "cnw", "cnb"),
+             (ca.proj_out.norm, "csnw", "csnb"), (ffn.proj_out.norm, "fsnw", "fsnb")]
+    return p, norms
+
+
+class TrainPack:
+    """Device images of the chain's parameters for one MldDenoiser (forward GEMV layout, transposed layout, vectors),
+    refreshed by ``seeme_den_train_pack`` before every forward."""
+
+    def __init__(self, den):
+        if den.num_heads != 1:
+            raise NotImplementedError("HIP training path: one attention head")
+        self.den = den
+        dev = den.query_pos.pe.device
+        layers, pe0, fnw, fnb, wg_total, vp_total = den._layout()
+        lay = _train_layout()
+        self.lay = lay
+        self.img_f = torch.zeros(wg_total, device=dev, dtype=torch.float32)
+        self.img_b = torch.zeros(lay["bwd_total"], device=dev, dtype=torch.float32)
+        self.vp = torch.zeros(vp_total, device=dev, dtype=torch.float32)
+        mats: List[int] = []
+        vecs = [(den.query_pos.pe, 256, pe0), (den.encoder.norm.weight, 256, fnw), (den.encoder.norm.bias, 256, fnb)]
+        self.params: List[torch.nn.Parameter] = [den.query_pos.pe, den.encoder.norm.weight, den.encoder.norm.bias]
+        self.index = {}            # (layer, name, 'w' | 'b' | 'nw' | 'nb') -> position in self.params
+        for l in range(5):
+            p, norms = _layer_params(den, l)
+            for name in _MATS:
+                if name in p:
+                    w, b, bname = p[name]
+                    mats.append(w.data_ptr())
+                    vecs.append((b, b.numel(), layers[l][bname]))
+                    self.index[(l, name, "w")] = len(self.params); self.params.append(w)
+                    self.index[(l, name, "b")] = len(self.params); self.params.append(b)
+                else:
+                    mats.append(0)
+            for i, (nm, wn, bn) in enumerate(norms):
+                vecs.append((nm.weight, 256, layers[l][wn]))
+                vecs.append((nm.bias, 256, layers[l][bn]))
+                self.index[(l, i, "nw")] = len(self.params); self.params.append(nm.weight)
+                self.index[(l, i, "nb")] = len(self.params); self.params.append(nm.bias)
+        for t in self.params:
+            L.require_cuda(t, "MldDenoiser parameter")
+        self._ptrs = (C.c_void_p * len(mats))(*mats)
+        self._vsrc = (C.c_void_p * len(vecs))(*[v[0].data_ptr() for v in vecs])
+        self._vn = (C.c_int * len(vecs))(*[int(v[1]) for v in vecs])
+        self._vdst = (C.c_int64 * len(vecs))(*[int(v[2]) for v in vecs])
+        self._nvec = len(vecs)
+        self._ptr_key = tuple(t.data_ptr() for t in self.params)
+        w = L.DenoiserWeights()
+        lay_dev = torch.tensor(den._layout_vals, dtype=torch.int64, device=dev)
+        w.wg, w.wdtype, w.vp, w.layout = self.img_f.data_ptr(), 0, self.vp.data_ptr(), lay_dev.data_ptr()
+        w.nhead, w.ff_sa, w.ff, w.sa_fold = 1, 1024, den.ff_size, 0
+        self.w, self._keep = w, lay_dev
+
+    def stale(self) -> bool:
+        return tuple(t.data_ptr() for t in self.params) != self._ptr_key
+
+    def refresh(self):
+        L.check(L.lib().seeme_den_train_pack(self._ptrs, self.img_f.data_ptr(), self.img_b.data_ptr(), self._vsrc, self._vn,
+                                             self._vdst, self._nvec, self.vp.data_ptr(), L.current_stream()), "seeme_den_train_pack")
+
+
+def _tables(den, cond_sf: torch.Tensor, emb: torch.Tensor):
+    """Differentiable table builders: ctab [B,N,5120], ttab [B,7680] in the layouts of include/seeme_hip.h."""
+    blocks = den.encoder.blocks()
+    cond = cond_sf.permute(1, 0, 2)                                                  # [B,N,256]
+    kv_w = torch.cat([b.sa_block.self_attn.in_proj_weight[256:] for b in blocks])    # [2560,256]: K|V per layer
+    kv_b = torch.cat([b.sa_block.self_attn.in_proj_bias[256:] for b in blocks])
+    sa_c = F.linear(cond, kv_w, kv_b)                                                # [B,N,2560]
+    ca_c = torch.cat([F.linear(F.layer_norm(cond, (256,), b.ca_block.text_norm.weight, b.ca_block.text_norm.bias),
+                               torch.cat([b.ca_block.key.weight, b.ca_block.value.weight]),
+                               torch.cat([b.ca_block.key.bias, b.ca_block.value.bias])) for b in blocks], dim=-1)
+    ctab = torch.cat([sa_c, ca_c], dim=-1).contiguous()
+    st_w = torch.cat([torch.cat([b.ca_block.proj_out.emb_layers[1].weight, b.ffn.proj_out.emb_layers[1].weight]) for b in blocks])
+    st_b = torch.cat([torch.cat([b.ca_block.proj_out.emb_layers[1].bias, b.ffn.proj_out.emb_layers[1].bias]) for b in blocks])
+    ttab = torch.cat([F.linear(emb, kv_w, kv_b), F.linear(F.silu(emb), st_w, st_b)], dim=-1).contiguous()
+    return ctab, ttab
+
+
+class _Chain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pack: TrainPack, noisy, ctab, ttab, *params):
+        B, N = noisy.shape[0], ctab.shape[1]
+        dev = noisy.device
+        pack.refresh()
+        lay = pack.lay
+        save = torch.empty(B, lay["DT_TOTAL"], device=dev, dtype=torch.float32)
+        out = torch.empty(B, 256, device=dev, dtype=torch.float32)
+        trow = torch.arange(B, device=dev, dtype=torch.int32)
+        a = L.SampleArgs()
+        a.B, a.N, a.steps, a.sched, a.cfg, a.guidance_scale = B, N, 1, L.SCHED_NONE, 0, 1.0
+        lat = noisy.contiguous()
+        a.latents, a.ctab, a.ttab, a.trow, a.trow_per_sample = lat.data_ptr(), ctab.data_ptr(), ttab.data_ptr(), trow.data_ptr(), 1
+        a.coef, a.noise, a.out, a.catab = 0, 0, out.data_ptr(), 0
+        a.save, a.force_query = save.data_ptr(), 1
+        L.check(L.lib().seeme_denoiser_sample(C.byref(pack.w), C.byref(a), L.current_stream()), "seeme_denoiser_sample")
+        ctx.pack, ctx.N = pack, N
+        ctx.save_for_backward(save, ctab, ttab, trow)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        pack = ctx.pack
+        save, ctab, ttab, trow = ctx.saved_tensors
+        B, N, dev = save.shape[0], ctx.N, save.device
+        lay = pack.lay
+        gout = torch.zeros(B, lay["DB_TOTAL"], device=dev, dtype=torch.float32)
+        dctab, dttab = torch.empty_like(ctab), torch.empty_like(ttab)
+        L.check(L.lib().seeme_denoiser_backward(C.byref(pack.w), pack.img_b.data_ptr(), B, N, save.data_ptr(), ctab.data_ptr(),
+                                                 ttab.data_ptr(), trow.data_ptr(), dout.contiguous().data_ptr(), gout.data_ptr(),
+                                                 dctab.data_ptr(), dttab.data_ptr(), L.current_stream()), "seeme_denoiser_backward")
+        DBL = lay["DB_LAYER"]
+        colsum = gout.sum(0)                                               # every bias / LayerNorm gradient at once
+        G = gout[:, : 5 * DBL].view(B, 5, DBL)
+        grads = [None] * len(pack.params)
+        # dW = sum_b dy_b x_b^T: one batched GEMM per matrix type (5 layers stacked)
+        for name, (xo, K, yo, Nn) in _LIN.items():
+            ls = [l for l in range(5) if (l, name, "w") in pack.index]
+            Y = G[:, ls, _DB[yo]:_DB[yo] + Nn].permute(1, 2, 0)            # [L, N, B]
+            X = G[:, ls, _DB[xo]:_DB[xo] + K].permute(1, 0, 2)             # [L, B, K]
+            dW = torch.bmm(Y, X)
+            for i, l in enumerate(ls):
+                grads[pack.index[(l, name, "w")]] = dW[i]
+                o = l * DBL + _DB[yo]
+                grads[pack.index[(l, name, "b")]] = colsum[o:o + Nn]
+        for l in range(5):
+            for i in range(5):
+                o = l * DBL + _DB["LN"] + i * 512
+                grads[pack.index[(l, i, "nw")]] = colsum[o:o + 256]
+                grads[pack.index[(l, i, "nb")]] = colsum[o + 256:o + 512]
+        fin = 5 * DBL
+        dpe = torch.zeros_like(pack.params[0])
+        dpe[0, 0] = colsum[fin + 512:fin + 768]                            # query_pos.pe row 0 (added to the latent token)
+        grads[0], grads[1], grads[2] = dpe, colsum[fin:fin + 256], colsum[fin + 256:fin + 512]
+        dnoisy = gout[:, fin + 512:fin + 768]
+        return (None, dnoisy, dctab, dttab, *grads)
+
+
+def hip_train_supported(den, n_tokens: int) -> bool:
+    return den.num_heads == 1 and 1 <= n_tokens <= 4 and den.ff_size == 128 and den.query_pos.pe.is_cuda
+
+
+def denoiser_forward_hip_train(den, sample: torch.Tensor, timesteps: torch.Tensor, cond_sf: torch.Tensor) -> torch.Tensor:
+    """sample [B,1,256]; timesteps [B]; cond_sf [N,B,256] (seq-first) -> noise prediction [B,1,256], differentiable
+    w.r.t. every denoiser parameter and the condition tokens."""
+    pack = getattr(den, "_train_pack", None)
+    if pack is None or pack.stale():
+        pack = TrainPack(den)
+        den._train_pack = pack
+    B = sample.shape[0]
+    tfeat = timestep_features(timesteps.to(sample.device), den.text_encoded_dim, den.flip_sin_to_cos, den.freq_shift).to(torch.float32)
+    te = den.time_embedding                                                 # TimestepEmbedding: Linear -> SiLU -> Linear
+    emb = F.linear(F.silu(F.linear(tfeat, te.linear_1.weight, te.linear_1.bias)), te.linear_2.weight, te.linear_2.bias)   # [B,256]
+    ctab, ttab = _tables(den, cond_sf, emb)
+    out = _Chain.apply(pack, sample.reshape(B, 256), ctab, ttab, *pack.params)
+    return out.reshape(B, 1, 256)

@@ -249,6 +249,7 @@ class MLD(nn.Module):
         self.predict_transl = cfg.TRAIN.ABLATION.PREDICT_TRANSL
         self.data_type = cfg.DATA_TYPE
         self.see_future = cfg.TEST.get("SEE_FUTURE", False)
+        self.hip_backward = cfg.TRAIN.get("HIP_BACKWARD", True)   # hand-written backward of the denoiser chain (one head)
         self.pose_estimation_task = cfg.TEST.get("POSE_ESTIMATION_TASK", False)      # mld.py:116
         if self.name_dataset == "egobody":                               # mld.py:122-125
             self.nfeats = 75 if self.predict_transl else 72
@@ -350,7 +351,11 @@ class MLD(nn.Module):
         timesteps = timesteps.long()
         noisy = self.noise_scheduler.add_noise(latents.clone(), noise, timesteps)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.denoiser.parameters()):
-            noise_pred = denoiser_forward_torch(self.denoiser, noisy, timesteps, encoder_hidden_states)  # autograd
+            from .denoiser_train import denoiser_forward_hip_train, hip_train_supported
+            if self.hip_backward and noisy.is_cuda and hip_train_supported(self.denoiser, encoder_hidden_states.shape[0]):
+                noise_pred = denoiser_forward_hip_train(self.denoiser, noisy, timesteps, encoder_hidden_states)  # HIP fwd + bwd
+            else:
+                noise_pred = denoiser_forward_torch(self.denoiser, noisy, timesteps, encoder_hidden_states)  # autograd twin
         else:
             noise_pred = self.denoiser(sample=noisy, timestep=timesteps, encoder_hidden_states=encoder_hidden_states,
                                        lengths=lengths)[0]                                              # HIP

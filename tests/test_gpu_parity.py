@@ -588,3 +588,52 @@ def test_ego_eval_variants(dev):
     m2 = MLD(cfg2, dm, smpl_model=SMPL.synthetic(1234)).to(dev).eval()
     rs2 = m2.ego_eval(dm.batch(2, idx=2))
     assert rs2["m_rst"].shape[1] == 12 and rs2["lengths"] == [12, 12] and torch.isfinite(rs2["joints_rst"]).all()
+
+
+@pytest.mark.parametrize("N", [1, 2])
+def test_hip_backward_matches_autograd(dev, N):
+    """Hand-written backward of the denoiser chain (k_den_bwd + host batch reductions) vs PyTorch autograd over the
+    differentiable twin: loss, every parameter gradient and the gradient of the condition tokens."""
+    from seeme_amd.denoiser_autograd import denoiser_forward_torch
+    from seeme_amd.denoiser_train import denoiser_forward_hip_train
+    den = make_den(dev, cond=("text", "scene", "interactee"))
+    den.train()
+    g = torch.Generator(device="cpu").manual_seed(11 + N)
+    B = 5
+    sample = torch.randn(B, 1, 256, generator=g).to(dev)
+    cond = torch.randn(N, B, 256, generator=g).to(dev).requires_grad_(True)
+    t = torch.tensor([3, 999, 250, 0, 600], device=dev)
+    target = torch.randn(B, 1, 256, generator=g).to(dev)
+
+    def run(fn):
+        for p in den.parameters():
+            p.grad = None
+        cond.grad = None
+        out = fn(den, sample, t, cond)
+        loss = torch.nn.functional.mse_loss(out, target)
+        loss.backward()
+        return out.detach(), float(loss), {k: (p.grad.clone() if p.grad is not None else None) for k, p in den.named_parameters()}, cond.grad.clone()
+
+    o_ref, l_ref, g_ref, c_ref = run(denoiser_forward_torch)
+    o_hip, l_hip, g_hip, c_hip = run(denoiser_forward_hip_train)
+    assert rel_err(o_hip.cpu().numpy(), o_ref.cpu().numpy()) < TOL_F32 and abs(l_hip - l_ref) < 1e-5 * max(1.0, abs(l_ref))
+    assert rel_err(c_hip.cpu().numpy(), c_ref.cpu().numpy()) < 2e-4
+    worst = ("", 0.0)
+    gmax = max(float(gr.abs().max()) for gr in g_ref.values() if gr is not None)
+    for k, gr in g_ref.items():
+        if gr is None:
+            assert g_hip[k] is None or float(g_hip[k].abs().max()) == 0.0, k
+            continue
+        assert g_hip[k] is not None, f"no gradient for {k}"
+        if float(gr.abs().max()) < 1e-6 * gmax:
+            # numerically zero in the reference too (one condition token: the query path has no influence, its exact
+            # gradient is 0 and autograd returns rounding noise) -- only require the same order of nothing
+            assert float(g_hip[k].abs().max()) < 1e-5 * gmax, k
+            continue
+        e = rel_err(g_hip[k].cpu().numpy(), gr.cpu().numpy())
+        if e > 1e-3:
+            print(f"   grad mismatch {k}: rel err {e:.3e}")
+        if e > worst[1]:
+            worst = (k, e)
+    print(f"HIP backward vs autograd (N={N}): worst parameter-gradient rel err {worst[1]:.3e} at {worst[0]}")
+    assert worst[1] < 5e-4, worst
