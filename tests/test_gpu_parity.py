@@ -637,3 +637,11 @@ def test_hip_backward_matches_autograd(dev, N):
             worst = (k, e)
     print(f"HIP backward vs autograd (N={N}): worst parameter-gradient rel err {worst[1]:.3e} at {worst[0]}")
     assert worst[1] < 5e-4, worst
+    # gradient accumulation: a second backward without zero_grad adds to the first (the .grad views are still in use)
+    out = denoiser_forward_hip_train(den, sample, t, cond)
+    torch.nn.functional.mse_loss(out, target).backward()
+    k = "encoder.middle_block.sa_block.linear1.weight"
+    acc = dict(den.named_parameters())[k].grad
+    assert rel_err(acc.cpu().numpy(), 2 * g_hip[k].cpu().numpy()) < 1e-5
+    kin = "encoder.middle_block.sa_block.self_attn.in_proj_weight"          # shared by the chain and the tables
+    assert rel_err(dict(den.named_parameters())[kin].grad.cpu().numpy(), 2 * g_hip[kin].cpu().numpy()) < 1e-5
