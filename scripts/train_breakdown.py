@@ -9,8 +9,10 @@ from seeme_amd.weights_recipe import load_recipe_
 dev = torch.device("cuda", 0)
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = parse_config(os.path.join(repo, "configs", "config_mld_scene.yaml"))
-if len(sys.argv) > 1 and sys.argv[1] == "twin":
+if "twin" in sys.argv[1:]:
     cfg.TRAIN.HIP_BACKWARD = False
+if "vae16" in sys.argv[1:]:
+    cfg.TRAIN.FROZEN_VAE_PRECISION = "fp16"
 dm = SyntheticEgoDataModule(nfeats=75, T=196, n_points=20000, device=dev)
 model = MLD(cfg, dm, smpl_model=SMPL.synthetic(1234))
 load_recipe_(model.vae), load_recipe_(model.denoiser), load_recipe_(model.proscene.scene_enc)

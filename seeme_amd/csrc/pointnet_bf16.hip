@@ -17,6 +17,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define PN_MT 128          // points per workgroup
+#define PN_THREADS 512      // 8 waves
 #define PN_H 256           // hidden width
 #define PN_PADB 16         // bf16 elements of row padding (2 x 16-byte slots: conflict-free ds_read_b128)
 
@@ -94,9 +95,11 @@ struct PnBlockArgs {
 };
 
 template <bool FIRST>
-__global__ __launch_bounds__(256) void k_pn_block(const PnBlockArgs a) {
+__global__ __launch_bounds__(PN_THREADS) void k_pn_block(const PnBlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // 8 waves = 2 row halves x 4 column quarters: two waves per SIMD, so one wave's MFMAs cover the other's LDS / L2 latency
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
+    const int mh = wave >> 2, nq = wave & 3, row0 = mh * (PN_MT / 2);
     const int scene = blockIdx.y, p0 = blockIdx.x * PN_MT;
     const int rows_valid = min(PN_MT, a.P - p0);
     constexpr int K = FIRST ? 512 : 256;
@@ -111,30 +114,22 @@ __global__ __launch_bounds__(256) void k_pn_block(const PnBlockArgs a) {
 
     // x512 = fc_pos_0(p) (K = 3: plain FMAs) as bf16 into T0: thread <-> columns tid, tid+256 (weights in
     // registers), points broadcast from LDS, consecutive lanes write consecutive 2-byte elements
-    float pw[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, pb[2] = {0.f, 0.f};
+    float pw[3] = {0.f, 0.f, 0.f}, pb = 0.f;
     if (FIRST) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c = tid + 256 * h;
-            pw[h][0] = a.pos_w[c * 16 + 0]; pw[h][1] = a.pos_w[c * 16 + 1]; pw[h][2] = a.pos_w[c * 16 + 2];
-            pb[h] = a.pos_b[c];
-        }
+        pw[0] = a.pos_w[tid * 16 + 0]; pw[1] = a.pos_w[tid * 16 + 1]; pw[2] = a.pos_w[tid * 16 + 2];
+        pb = a.pos_b[tid];
     }
     auto gen_first = [&](bool do_relu) {
         for (int row = 0; row < PN_MT; ++row) {
             const float px = spts[row * 3 + 0], py = spts[row * 3 + 1], pz = spts[row * 3 + 2];
-            const bool ok = row < rows_valid;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float v = ok ? pb[h] + pw[h][0] * px + pw[h][1] * py + pw[h][2] * pz : 0.f;
-                if (do_relu) v = fmaxf(v, 0.f);
-                T0[row * LDA + tid + 256 * h] = f2bf(v);
-            }
+            float v = row < rows_valid ? pb + pw[0] * px + pw[1] * py + pw[2] * pz : 0.f;
+            if (do_relu) v = fmaxf(v, 0.f);
+            T0[row * LDA + tid] = f2bf(v);
         }
     };
 
     if (FIRST) {
-        for (int i = tid; i < PN_MT * 3; i += 256)
+        for (int i = tid; i < PN_MT * 3; i += PN_THREADS)
             spts[i] = (i / 3 < rows_valid) ? a.points[((size_t)scene * a.P + p0) * 3 + i] : 0.f;
         __syncthreads();
         gen_first(true);
@@ -142,18 +137,18 @@ __global__ __launch_bounds__(256) void k_pn_block(const PnBlockArgs a) {
         // stage raw + relu copies of the bf16 input tile (8 bf16 = 16 B per thread step)
         const unsigned short* xin = a.x + ((size_t)scene * a.P + p0) * PN_H;
         // all 16 row-loads of a thread are in flight together (the tile is one HBM round trip, not sixteen)
-        constexpr int NIT = PN_MT * (PN_H / 8) / 256;
+        constexpr int NIT = PN_MT * (PN_H / 8) / PN_THREADS;
         uint4 v[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 256, row = idx >> 5, c8 = (idx & 31) * 8;
+            const int idx = tid + it * PN_THREADS, row = idx >> 5, c8 = (idx & 31) * 8;
             v[it] = make_uint4(0u, 0u, 0u, 0u);
             if (row < rows_valid) v[it] = *reinterpret_cast<const uint4*>(xin + (size_t)row * PN_H + c8);
         }
         auto relu2 = [](unsigned u) { const unsigned m = (u >> 15) & 0x00010001u; return u & ~(m * 0xFFFFu); };   // packed bf16 relu
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 256, row = idx >> 5, c8 = (idx & 31) * 8;
+            const int idx = tid + it * PN_THREADS, row = idx >> 5, c8 = (idx & 31) * 8;
             *reinterpret_cast<uint4*>(T0 + row * LDA + c8) = v[it];
             *reinterpret_cast<uint4*>(T1 + row * LDA + c8) = make_uint4(relu2(v[it].x), relu2(v[it].y), relu2(v[it].z), relu2(v[it].w));
         }
@@ -161,48 +156,48 @@ __global__ __launch_bounds__(256) void k_pn_block(const PnBlockArgs a) {
     __syncthreads();
 
     // ---- fc_0 on relu(x): wave w owns hidden columns [64w, 64w+64)
-    f32x4 acc[8][4];
+    f32x4 acc[4][4];
     acc_zero(acc);
-    tile_gemm_bf16<8, 4>(FIRST ? T0 : T1, LDA, a.w0, a.ks0, wave * 4, K / 32, acc);
+    tile_gemm_bf16<4, 4>((FIRST ? T0 : T1) + row0 * LDA, LDA, a.w0, a.ks0, nq * 4, K / 32, acc);
     __syncthreads();                                       // all waves done reading the relu tile
     {
         unsigned short* Hs = FIRST ? T0 : T1;              // hidden tile [128][LDH] overwrites it
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int c = wave * 64 + nt * 16 + r;
+            const int c = nq * 64 + nt * 16 + r;
             const float bv = a.b0[c] + (FIRST ? 0.f : a.v0[(size_t)scene * PN_H + c]);
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) Hs[(mt * 16 + 4 * kq + i) * LDH + c] = f2bf(fmaxf(acc[mt][nt][i] + bv, 0.f));
+                for (int i = 0; i < 4; ++i) Hs[(row0 + mt * 16 + 4 * kq + i) * LDH + c] = f2bf(fmaxf(acc[mt][nt][i] + bv, 0.f));
         }
     }
     __syncthreads();
     // ---- out = fc_1(hid) + shortcut(x), one accumulator
     acc_zero(acc);
-    tile_gemm_bf16<8, 4>(FIRST ? T0 : T1, LDH, a.w1, PN_H / 32, wave * 4, PN_H / 32, acc);
+    tile_gemm_bf16<4, 4>((FIRST ? T0 : T1) + row0 * LDH, LDH, a.w1, PN_H / 32, nq * 4, PN_H / 32, acc);
     if (FIRST) {
         __syncthreads();                                   // hidden tile consumed
         gen_first(false);                                  // raw x512 for the shortcut
         __syncthreads();
     }
-    tile_gemm_bf16<8, 4>(T0, LDA, a.ws, a.kss, wave * 4, K / 32, acc);
+    tile_gemm_bf16<4, 4>(T0 + row0 * LDA, LDA, a.ws, a.kss, nq * 4, K / 32, acc);
     __syncthreads();                                       // LDS tiles dead: reuse as the fp32 epilogue tile
     constexpr int LDC = PN_H + 8;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int c = wave * 64 + nt * 16 + r;
+        const int c = nq * 64 + nt * 16 + r;
         const float bv = a.b1[c] + (FIRST ? 0.f : a.vs[(size_t)scene * PN_H + c]);
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) Cs[(mt * 16 + 4 * kq + i) * LDC + c] = acc[mt][nt][i] + bv;
+            for (int i = 0; i < 4; ++i) Cs[(row0 + mt * 16 + 4 * kq + i) * LDC + c] = acc[mt][nt][i] + bv;
     }
     __syncthreads();
     // ---- epilogue: bf16 rows to HBM (512 B per row, coalesced) and the tile's column max -> per-scene pool
     if (a.out != nullptr) {
         unsigned short* op = a.out + ((size_t)scene * a.P + p0) * PN_H;
-        for (int idx = tid; idx < rows_valid * (PN_H / 4); idx += 256) {
+        for (int idx = tid; idx < rows_valid * (PN_H / 4); idx += PN_THREADS) {
             const int row = idx >> 6, c4 = (idx & 63) * 4;
             const float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c4);
             const unsigned lo = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16), hi = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
@@ -210,12 +205,12 @@ __global__ __launch_bounds__(256) void k_pn_block(const PnBlockArgs a) {
         }
     }
     {
-        float m = -INFINITY;                               // thread <-> column
-        for (int row = 0; row < rows_valid; ++row) m = fmaxf(m, Cs[row * LDC + tid]);
+        float m = -INFINITY;                               // thread <-> (column, row parity): two atomics per column
+        for (int row = tid >> 8; row < rows_valid; row += 2) m = fmaxf(m, Cs[row * LDC + (tid & 255)]);
         // the next block consumes the pooled vector through bf16 activations of equal rounding: pool the value that
         // is actually stored
         if (a.out != nullptr) m = bf2f(f2bf(m));
-        atomic_max_f32(a.pool + (size_t)scene * PN_H + tid, m);
+        atomic_max_f32(a.pool + (size_t)scene * PN_H + (tid & 255), m);
     }
 }
 
@@ -265,14 +260,14 @@ extern "C" int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const S
         a.out = (i < 3) ? nxt : nullptr;            // the last block only feeds the final pool
         if (i == 0) {
             a.points = points; a.pos_w = w->pos_w; a.pos_b = w->pos_b;
-            hipLaunchKernelGGL((k_pn_block<true>), grid, dim3(256), lds_first, st, a);
+            hipLaunchKernelGGL((k_pn_block<true>), grid, dim3(PN_THREADS), lds_first, st, a);
         } else {
             const float* pool_prev = pools + (size_t)(i - 1) * B * PN_H;
             // pooled halves in fp32: v0 = W0[:,256:] relu(pool), vs = Ws[:,256:] pool
             if ((rc = small_lin(st, pool_prev, w->fc0_w[i] + PN_H, 512, v0, B, SEEME_ACT_RELU))) return rc;
             if ((rc = small_lin(st, pool_prev, w->sc_w[i] + PN_H, 512, vs, B, SEEME_ACT_NONE))) return rc;
             a.x = cur; a.v0 = v0; a.vs = vs;
-            hipLaunchKernelGGL((k_pn_block<false>), grid, dim3(256), lds_next, st, a);
+            hipLaunchKernelGGL((k_pn_block<false>), grid, dim3(PN_THREADS), lds_next, st, a);
         }
         if ((rc = seeme_check_launch("k_pn_block"))) return rc;
         if (i > 0) { unsigned short* t = cur; cur = nxt; nxt = t; } else { cur = nxt; nxt = xa; }

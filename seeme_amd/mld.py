@@ -279,6 +279,8 @@ class MLD(nn.Module):
         if self.stage == "diffusion":                                     # :267-271
             for p in self.vae.parameters():
                 p.requires_grad = False
+            # the frozen VAE only produces latents here: TRAIN.FROZEN_VAE_PRECISION fp16 runs it on the fp16-MFMA path
+            self.vae.precision = cfg.TRAIN.get("FROZEN_VAE_PRECISION", self.vae.precision)
         self.denoiser = instantiate_from_config(cfg.model.denoiser)       # :282
         if not self.predict_epsilon:
             cfg.model.scheduler.params["prediction_type"] = "sample"
