@@ -403,10 +403,22 @@ class MLD(nn.Module):
         lengths = [feats_ref.shape[1]] * feats_ref.shape[0]
         idx = 0 if self.estimate == "wearer" else 1
         f_ref = self._wearer_features(feats_ref, transl, idx)
-        z, dist_m = self.vae.encode(f_ref, None, lengths)
-        feats_rst = self.vae.decode(z, lengths)
-        joints_ref = self._feats_to_joints(self.renorm(f_ref), beta[:, idx])
-        joints_rst = self._feats_to_joints(self.renorm(feats_rst), beta[:, idx])
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.vae.parameters()):
+            # stage-1 training: differentiable twins of the VAE and the SMPL joint regressor (PyTorch-ROCm autograd;
+            # a hand-written backward for this stage is not built)
+            from .vae_autograd import vae_encode_torch, vae_decode_torch
+            mu, std = vae_encode_torch(self.vae, f_ref, lengths)
+            dist_m = torch.distributions.Normal(mu, std, validate_args=False)
+            z = dist_m.rsample()
+            feats_rst = vae_decode_torch(self.vae, z, lengths)
+            with torch.no_grad():
+                joints_ref = self._feats_to_joints(self.renorm(f_ref), beta[:, idx])
+            joints_rst = self._feats_to_joints_torch(self.renorm(feats_rst), beta[:, idx])
+        else:
+            z, dist_m = self.vae.encode(f_ref, None, lengths)
+            feats_rst = self.vae.decode(z, lengths)
+            joints_ref = self._feats_to_joints(self.renorm(f_ref), beta[:, idx])
+            joints_rst = self._feats_to_joints(self.renorm(feats_rst), beta[:, idx])
         dist_ref = torch.distributions.Normal(torch.zeros_like(dist_m.loc), torch.ones_like(dist_m.scale))
         return {"m_ref": f_ref, "m_rst": feats_rst, "joints_ref": joints_ref, "joints_rst": joints_rst,
                 "dist_m": dist_m, "dist_ref": dist_ref, "lat_m": z.permute(1, 0, 2)}
@@ -433,6 +445,19 @@ class MLD(nn.Module):
         if want_vertices:
             return joints, out.vertices.reshape(B, T, -1, 3)
         return joints
+
+    def _feats_to_joints_torch(self, feats, betas):
+        """Differentiable version of _feats_to_joints for stage-1 training ('angle' data: axis-angle pose)."""
+        from .vae_autograd import smpl_joints_torch
+        if self.data_type != "angle":
+            raise NotImplementedError("stage-1 training twin: DATA_TYPE 'angle'")
+        B, T, _ = feats.shape
+        nb = 69 if self.name_dataset == "egobody" else 63
+        pose = feats[:, :, :3 + nb].reshape(B * T, 3 + nb)
+        if nb < 69:                                                        # GIMO pads 21 -> 23 joints (mld.py:807-813)
+            pose = torch.cat([pose, torch.zeros(B * T, 69 - nb, device=pose.device, dtype=pose.dtype)], dim=1)
+        tr = feats[:, :, -3:].reshape(B * T, 3) if self.predict_transl else None
+        return smpl_joints_torch(self.smpl_model, betas.reshape(-1, 10).float(), pose.float(), tr).reshape(B, T, 24, 3)
 
     # ------------------------------------------------------------------ evaluation (mld.py:1076-1905, live part)
     @torch.no_grad()

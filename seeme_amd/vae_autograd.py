@@ -1,0 +1,130 @@
+"""Differentiable twins for STAGE-1 training (``TRAIN.STAGE: vae``): the motion VAE and the SMPL joint regressor in
+plain PyTorch ops on the same parameters / buffers as the HIP modules, so that ``MLD.train_vae_forward`` has a backward
+(PyTorch-ROCm autograd on the device).  Inference and stage-2 never route through here; a hand-written backward for this
+stage is not built yet.  Checked against the HIP forward in
+tests/test_gpu_parity.py::test_vae_autograd_twin_matches_hip.
+
+Reference: mld_vae.py:128-256, cross_attention.py:41-147,281-367 (eval-mode arithmetic: dropout off, as the HIP path);
+smplx lbs: shape blend -> joint regression -> Rodrigues -> pose blend is irrelevant for joints ->
+kinematic chain -> posed joints + translation.
+"""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import torch
+import torch.nn.functional as F
+
+
+def _mha(lp, q_in, k_in, v_in, nhead: int, key_padding_mask=None):
+    """nn.MultiheadAttention arithmetic, batch-first [B,S,D]; key_padding_mask bool [B,Sk], True = ignore."""
+    w, b = lp.in_proj_weight, lp.in_proj_bias
+    D = q_in.shape[-1]
+    q = F.linear(q_in, w[:D], b[:D])
+    k = F.linear(k_in, w[D:2 * D], b[D:2 * D])
+    v = F.linear(v_in, w[2 * D:], b[2 * D:])
+    B, Sq, _ = q.shape
+    hd = D // nhead
+    q = q.view(B, Sq, nhead, hd).transpose(1, 2)
+    k = k.view(B, -1, nhead, hd).transpose(1, 2)
+    v = v.view(B, -1, nhead, hd).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    if key_padding_mask is not None:
+        s = s.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+    o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, Sq, D)
+    return F.linear(o, lp.out_proj.weight, lp.out_proj.bias)
+
+
+def _ln(x, n):
+    return F.layer_norm(x, (x.shape[-1],), n.weight, n.bias)
+
+
+def _enc_layer(lp, x, nhead, kpm):                                   # forward_post, cross_attention.py:281-294
+    x = _ln(x + _mha(lp.self_attn, x, x, x, nhead, kpm), lp.norm1)
+    return _ln(x + F.linear(F.gelu(F.linear(x, lp.linear1.weight, lp.linear1.bias)), lp.linear2.weight, lp.linear2.bias), lp.norm2)
+
+
+def _dec_layer(lp, x, mem, nhead, kpm):                              # forward_post, cross_attention.py:345-367
+    x = _ln(x + _mha(lp.self_attn, x, x, x, nhead, kpm), lp.norm1)
+    x = _ln(x + _mha(lp.multihead_attn, x, mem, mem, nhead, None), lp.norm2)
+    return _ln(x + F.linear(F.gelu(F.linear(x, lp.linear1.weight, lp.linear1.bias)), lp.linear2.weight, lp.linear2.bias), lp.norm3)
+
+
+def _skip_stack(stack, x, layer_fn):                                  # cross_attention.py:46-65,118-147
+    nb = len(stack.input_blocks)
+    xs = []
+    for i in range(nb):
+        x = layer_fn(stack.input_blocks[i], x)
+        xs.append(x)
+    x = layer_fn(stack.middle_block, x)
+    for i in range(nb):
+        x = F.linear(torch.cat([x, xs.pop()], dim=-1), stack.linear_blocks[i].weight, stack.linear_blocks[i].bias)
+        x = layer_fn(stack.output_blocks[i], x)
+    return _ln(x, stack.norm)
+
+
+def _mask(lengths: List[int], device):
+    lens = torch.as_tensor(lengths, device=device)
+    return torch.arange(int(max(lengths)), device=device)[None, :] < lens[:, None]
+
+
+def vae_encode_torch(vae, features: torch.Tensor, lengths: List[int]):
+    """features [B,T,F] -> (mu [1,B,256], std [1,B,256]) (mld_vae.py:128-193)."""
+    B = features.shape[0]
+    nhead = vae.encoder.input_blocks[0].self_attn.num_heads
+    mask = _mask(lengths, features.device)
+    x = F.linear(features, vae.skel_embedding.weight, vae.skel_embedding.bias)
+    tok = vae.global_motion_token[None].expand(B, -1, -1)
+    aug = torch.cat([torch.ones(B, tok.shape[1], dtype=torch.bool, device=x.device), mask], dim=1)
+    xseq = torch.cat([tok, x], dim=1)
+    xseq = xseq + vae.query_pos_encoder.pe[: xseq.shape[1], 0][None]
+    out = _skip_stack(vae.encoder, xseq, lambda lp, h: _enc_layer(lp, h, nhead, ~aug))
+    mu, logvar = out[:, 0], out[:, 1]
+    return mu[None], logvar.exp().pow(0.5)[None]
+
+
+def vae_decode_torch(vae, z: torch.Tensor, lengths: List[int]):
+    """z [1,B,256] -> feats [B,T,F] (mld_vae.py:195-256, arch encoder_decoder; padded frames not zeroed, :253)."""
+    nhead = vae.decoder.input_blocks[0].self_attn.num_heads
+    mask = _mask(lengths, z.device)
+    B, T = mask.shape
+    q = vae.query_pos_decoder.pe[:T, 0][None].expand(B, -1, -1)
+    mem = z.permute(1, 0, 2)
+    out = _skip_stack(vae.decoder, q, lambda lp, h: _dec_layer(lp, h, mem, nhead, ~mask))
+    return F.linear(out, vae.final_layer.weight, vae.final_layer.bias)
+
+
+def _rodrigues(aa: torch.Tensor) -> torch.Tensor:
+    """Axis-angle [M,3] -> rotation matrices [M,3,3] (smplx batch_rodrigues: angle = ||aa + 1e-8||)."""
+    angle = torch.norm(aa + 1e-8, dim=1, keepdim=True)
+    d = aa / angle
+    c, s = torch.cos(angle)[:, None], torch.sin(angle)[:, None]
+    rx, ry, rz = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    z = torch.zeros_like(rx)
+    K = torch.cat([z, -rz, ry, rz, z, -rx, -ry, rx, z], dim=1).view(-1, 3, 3)
+    eye = torch.eye(3, device=aa.device, dtype=aa.dtype)[None]
+    return eye + s * K + (1 - c) * (K @ K)
+
+
+def smpl_joints_torch(smpl, betas: torch.Tensor, pose_aa: torch.Tensor, transl: torch.Tensor = None) -> torch.Tensor:
+    """The 24 posed SMPL joints [M,24,3], differentiable w.r.t. pose and translation (betas too).
+    pose_aa [M,72] = global_orient | body_pose."""
+    M = pose_aa.shape[0]
+    # rest joints = J_regressor (v_template + shapedirs betas), with the regressor folded in
+    cache = getattr(smpl, "_joint_fold", None)
+    if cache is None or cache[0].device != betas.device:
+        cache = (smpl.J_regressor @ smpl.v_template, torch.einsum("jv,vkl->jkl", smpl.J_regressor, smpl.shapedirs))
+        smpl._joint_fold = cache
+    J = cache[0][None] + torch.einsum("jkl,bl->bjk", cache[1], betas)                # [M,24,3]
+    R = _rodrigues(pose_aa.reshape(-1, 3)).view(M, 24, 3, 3)
+    parents = smpl.parents.tolist()
+    rel = J.clone()
+    rel[:, 1:] = J[:, 1:] - J[:, parents[1:]]
+    Tm = torch.cat([torch.cat([R, rel[..., None]], dim=-1),
+                    torch.tensor([0.0, 0.0, 0.0, 1.0], device=J.device, dtype=J.dtype).expand(M, 24, 1, 4)], dim=-2)   # [M,24,4,4]
+    chain = [Tm[:, 0]]
+    for i in range(1, 24):
+        chain.append(chain[parents[i]] @ Tm[:, i])
+    posed = torch.stack(chain, dim=1)[:, :, :3, 3]
+    return posed if transl is None else posed + transl[:, None, :]

@@ -645,3 +645,37 @@ def test_hip_backward_matches_autograd(dev, N):
     assert rel_err(acc.cpu().numpy(), 2 * g_hip[k].cpu().numpy()) < 1e-5
     kin = "encoder.middle_block.sa_block.self_attn.in_proj_weight"          # shared by the chain and the tables
     assert rel_err(dict(den.named_parameters())[kin].grad.cpu().numpy(), 2 * g_hip[kin].cpu().numpy()) < 1e-5
+
+
+def test_vae_autograd_twin_matches_hip_and_stage1_trains(dev):
+    """Stage-1 twins (seeme_amd/vae_autograd.py): same numbers as the HIP VAE / SMPL forward, and a stage-1 training step
+    (recons + joints + KL losses, mld/models/losses/mld.py:113-156) produces finite gradients and a decreasing loss."""
+    from seeme_amd.vae_autograd import vae_encode_torch, vae_decode_torch, smpl_joints_torch
+    from seeme_amd.config import parse_config
+    from seeme_amd.mld import MLD, SyntheticEgoDataModule
+    from seeme_amd.smpl import SMPL
+    vae = make_vae(75, dev)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(3, 24, 75, generator=g).to(dev)
+    lengths = [24, 17, 24]
+    with torch.no_grad():
+        mu_t, std_t = vae_encode_torch(vae, x, lengths)
+        dist = vae.encode_dist(x, lengths)
+        assert rel_err(mu_t.cpu().numpy(), dist[0:1].cpu().numpy()) < TOL_F32
+        z = mu_t
+        assert rel_err(vae_decode_torch(vae, z, lengths).cpu().numpy(), vae.decode(z, lengths).cpu().numpy()) < TOL_F32
+        smpl = SMPL.synthetic(1234).to(dev)
+        betas, pose, tr = torch.randn(7, 10, generator=g).to(dev) * 0.5, torch.randn(7, 72, generator=g).to(dev) * 0.4, torch.randn(7, 3, generator=g).to(dev)
+        j_hip = smpl(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3], transl=tr, return_verts=False).joints[:, :24]
+        assert rel_err(smpl_joints_torch(smpl, betas, pose, tr).cpu().numpy(), j_hip.cpu().numpy()) < TOL_F32
+    cfg = parse_config(os.path.join(REPO, "configs", "config_vae_egobody.yaml"))
+    dm = SyntheticEgoDataModule(nfeats=75, T=24, device=dev)
+    model = MLD(cfg, dm, smpl_model=SMPL.synthetic(1234)).to(dev).train()
+    batch = dm.batch(4, idx=0)
+    losses = []
+    for _ in range(4):
+        loss = model.training_step(batch)
+        model.optimizer_step(loss)
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in model.vae.named_parameters() if "query_pos" not in n)
