@@ -274,6 +274,8 @@ class MLD(nn.Module):
             self.proscene = _SceneEncoderHolder()
             for p in self.proscene.parameters():
                 p.requires_grad = False
+            # frozen scene encoder: TRAIN.SCENE_PRECISION bf16 runs the fused bf16-MFMA PointNet blocks
+            self.proscene.scene_enc.precision = cfg.TRAIN.get("SCENE_PRECISION", self.proscene.scene_enc.precision)
             self.output_scene = nn.Sequential(nn.ReLU(), nn.Linear(512, 256))
         self.vae = instantiate_from_config(cfg.model.motion_vae)          # :264
         if self.stage == "diffusion":                                     # :267-271
