@@ -15,12 +15,11 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned short f2h(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
 
-template <int MTL, int NTL, typename LoadB>
+template <int MTL, int NTL, int PF, typename LoadB>
 __device__ __forceinline__ void tile_gemm_h16(const unsigned short* __restrict__ As, int lda, int K32, LoadB loadb,
                                               f32x4 (&acc)[MTL][NTL]) {
     const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
     const unsigned short* ap = As + r * lda + 8 * kq;
-    constexpr int PF = 2;
     uint4 br[PF][NTL];
 #pragma unroll
     for (int u = 0; u < PF; ++u)
@@ -54,11 +53,11 @@ __device__ __forceinline__ void tile_gemm_h16(const unsigned short* __restrict__
     }
 }
 // B fragments from fragment-packed weights: Wp[(ntile*kstride + kb)*64 + lane]; n-tiles clamped to ntiles-1
-template <int MTL, int NTL>
+template <int MTL, int NTL, int PF = 2>
 __device__ __forceinline__ void gemm_packed(const unsigned short* As, int lda, const uint4* __restrict__ Wp, int kstride,
                                             int ntile0, int ntiles, int K32, f32x4 (&acc)[MTL][NTL]) {
     const int lane = threadIdx.x & 63;
-    tile_gemm_h16<MTL, NTL>(As, lda, K32, [&](int nt, int kb) {
+    tile_gemm_h16<MTL, NTL, PF>(As, lda, K32, [&](int nt, int kb) {
         int t = ntile0 + nt; t = t < ntiles ? t : ntiles - 1;
         return Wp[((size_t)t * kstride + kb) * 64 + lane];
     }, acc);
@@ -68,7 +67,7 @@ template <int MTL, int NTL>
 __device__ __forceinline__ void gemm_rows(const unsigned short* As, int lda, const unsigned short* __restrict__ Bm, int ldb,
                                           int n0, int n_valid, int K32, f32x4 (&acc)[MTL][NTL]) {
     const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
-    tile_gemm_h16<MTL, NTL>(As, lda, K32, [&](int nt, int kb) {
+    tile_gemm_h16<MTL, NTL, 2>(As, lda, K32, [&](int nt, int kb) {
         int n = n0 + nt * 16 + r; n = n < n_valid ? n : n_valid - 1;
         return *reinterpret_cast<const uint4*>(Bm + (size_t)n * ldb + kb * 32 + 8 * kq);
     }, acc);
@@ -238,6 +237,70 @@ static int launch_linear_h(const LinearHArgs& ha, hipStream_t st) {
     SEEME_HIP(hipFuncSetAttribute((const void*)k_linear_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_linear_h, grid, dim3(256), lds, st, h2);
     return seeme_check_launch("k_linear_h");
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_qkv_h: the QKV projection of one transformer layer, [M,256] fp32 -> q | k fp16 rows [M][512] and V^T [B][256][spv],
+// as a 128-row x 256-column tile per workgroup (8 waves = 2 row halves x 4 column quarters).  Against the generic
+// 32-row tile: 4x fewer re-reads of the 128 KB weight chunk from L2, two waves per SIMD, no fp32 staging or epilogue
+// tile (the fp16 output tile reuses the operand tile's LDS).
+#define QKV_MT 128
+__global__ __launch_bounds__(512) void k_qkv_h(const LinearHArgs ha) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const SeemeLinearArgs& a = ha.k.a;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
+    const int mh = wave >> 2, nq = wave & 3;
+    constexpr int LDH = 256 + HPAD;
+    unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);            // [128][272] fp16 operand tile, later the output tile
+    const int m0 = blockIdx.x * QKV_MT, y = blockIdx.y;
+    {   // stage: 128 rows x 64 float4, all of a thread's loads in flight together
+        constexpr int NIT = QKV_MT * 64 / 512;
+        float4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 512, row = idx >> 6, c4 = idx & 63, m = m0 + row;
+            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < a.M) v[it] = *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + 4 * c4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 512, row = idx >> 6, c4 = idx & 63;
+            const unsigned lo = (unsigned)f2h(v[it].x) | ((unsigned)f2h(v[it].y) << 16), hi = (unsigned)f2h(v[it].z) | ((unsigned)f2h(v[it].w) << 16);
+            *reinterpret_cast<uint2*>(Ah + row * LDH + 4 * c4) = make_uint2(lo, hi);
+        }
+    }
+    __syncthreads();
+    f32x4 acc[4][4];
+    acc_zero(acc);
+    gemm_packed<4, 4>(Ah + mh * 64 * LDH, LDH, ha.wp, ha.kstride, y * 16 + nq * 4, ha.ntiles, 8, acc);
+    __syncthreads();                                                          // operand tile consumed: it becomes the output tile
+    acc_store_h16<4, 4>(acc, Ah + mh * 64 * LDH, LDH, nq * 64, a.bias + y * 256, SEEME_ACT_NONE);
+    __syncthreads();
+    if (y < 2) {            // q | k: fp16 rows, 16-byte coalesced stores
+        for (int idx = tid; idx < QKV_MT * 32; idx += 512) {
+            const int row = idx >> 5, c8 = (idx & 31) * 8, m = m0 + row;
+            if (m < a.M) *reinterpret_cast<uint4*>(ha.qk + (size_t)m * 512 + y * 256 + c8) = *reinterpret_cast<const uint4*>(Ah + row * LDH + c8);
+        }
+    } else {                // v -> transposed [b][d][s]: lanes <-> rows (consecutive s), loop over d
+        const int row = tid & 127, dg = tid >> 7, m = m0 + row;
+        if (m < a.M) {
+            const int b = m / ha.S, s2 = m - b * ha.S;
+            unsigned short* base = ha.vt + ((size_t)b * 256) * ha.spv + s2;
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) {
+                const int d = dg * 64 + j;
+                base[(size_t)d * ha.spv] = Ah[row * LDH + d];
+            }
+        }
+    }
+}
+static int launch_qkv_h(const LinearHArgs& ha, hipStream_t st) {
+    const SeemeLinearArgs& a = ha.k.a;
+    const size_t lds = (size_t)QKV_MT * (256 + HPAD) * 2;
+    dim3 grid((a.M + QKV_MT - 1) / QKV_MT, 3);
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_qkv_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_qkv_h, grid, dim3(512), lds, st, ha);
+    return seeme_check_launch("k_qkv_h");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -466,7 +529,7 @@ static int run_layer_h(hipStream_t st, const SeemeXfLayer& L, const SeemeXfLayer
     LinearHArgs q{};
     q.k.a.A = cur; q.k.a.lda = 256; q.k.a.K1 = 256; q.k.a.K = 256; q.k.a.bias = L.in_b; q.k.a.M = B * S; q.k.a.N = 768; q.k.a.eps = 1e-5f;
     q.wp = (const uint4*)H.in_w; q.kstride = 8; q.ntiles = 48; q.qkv_mode = 1; q.qk = ws.qk; q.vt = ws.vt; q.S = S; q.spv = ws.spv;
-    int rc = launch_linear_h(q, st);
+    int rc = ((reinterpret_cast<size_t>(cur) & 15) == 0) ? launch_qkv_h(q, st) : launch_linear_h(q, st);
     if (rc) return rc;
     AttnHArgs at{};
     at.qk = ws.qk; at.vt = ws.vt; at.res = cur; at.wo = (const uint4*)H.out_w; at.bo = L.out_b; at.ln_w = L.n1_w; at.ln_b = L.n1_b;
