@@ -63,11 +63,11 @@ __device__ __forceinline__ void gemm_packed(const unsigned short* As, int lda, c
     }, acc);
 }
 // B fragments from a row-major fp16 matrix Bm[n][k] (rows clamped to n_valid-1)
-template <int MTL, int NTL>
+template <int MTL, int NTL, int PF = 2>
 __device__ __forceinline__ void gemm_rows(const unsigned short* As, int lda, const unsigned short* __restrict__ Bm, int ldb,
                                           int n0, int n_valid, int K32, f32x4 (&acc)[MTL][NTL]) {
     const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
-    tile_gemm_h16<MTL, NTL, 2>(As, lda, K32, [&](int nt, int kb) {
+    tile_gemm_h16<MTL, NTL, PF>(As, lda, K32, [&](int nt, int kb) {
         int n = n0 + nt * 16 + r; n = n < n_valid ? n : n_valid - 1;
         return *reinterpret_cast<const uint4*>(Bm + (size_t)n * ldb + kb * 32 + 8 * kq);
     }, acc);
@@ -313,6 +313,9 @@ struct AttnHArgs {
     float scale, eps;
 };
 
+#ifndef ATT_PF
+#define ATT_PF 2    // k-blocks of B operands (K rows, V^T rows, W_o) in flight: the tile is latency-bound, not MFMA-bound
+#endif
 __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
         const int n0 = c0 + wave * 64;
         f32x4 acc[2][4];
         acc_zero(acc);
-        if (n0 < a.S) gemm_rows<2, 4>(Qh, ldq, Kmat, 512, n0, a.S, 8, acc);
+        if (n0 < a.S) gemm_rows<2, 4, ATT_PF>(Qh, ldq, Kmat, 512, n0, a.S, 8, acc);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int c = n0 + nt * 16 + r;
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
         f32x4 acc[2][4];
         acc_zero(acc);
         const int K32 = (n_valid_keys + 31) >> 5;
-        gemm_rows<2, 4>(Ph, ldph, a.vt + (size_t)b * 256 * a.spv, a.spv, wave * 64, 256, K32, acc);
+        gemm_rows<2, 4, ATT_PF>(Ph, ldph, a.vt + (size_t)b * 256 * a.spv, a.spv, wave * 64, 256, K32, acc);
         acc_store_h16<2, 4>(acc, Qh, ldq, wave * 64, nullptr, SEEME_ACT_NONE);
     }
     __syncthreads();
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
     {
         f32x4 acc[2][4];
         acc_zero(acc);
-        gemm_packed<2, 4>(Qh, ldq, a.wo, 8, wave * 4, 16, 8, acc);
+        gemm_packed<2, 4, ATT_PF>(Qh, ldq, a.wo, 8, wave * 4, 16, 8, acc);
         acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, a.bo, 0, 256, SEEME_ACT_NONE);
     }
     __syncthreads();
