@@ -14,6 +14,16 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 #define HPAD 16
 
 __device__ __forceinline__ unsigned short f2h(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
+// The fp16 path rounds its MFMA operands to 11 bits anyway: hardware transcendentals (1 ulp) and an erf polynomial
+// (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7) cost a fraction of the IEEE library forms on the vector ALU.
+__device__ __forceinline__ float h_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float h_gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    return 0.5f * x * (1.f + copysignf(1.f - poly * h_exp(-z * z), x));
+}
+__device__ __forceinline__ float h_act(float v, int act) { return act == SEEME_ACT_GELU ? h_gelu(v) : act_apply(v, act); }
 
 template <int MTL, int NTL, int PF, typename LoadB>
 __device__ __forceinline__ void tile_gemm_h16(const unsigned short* __restrict__ As, int lda, int K32, LoadB loadb,
@@ -84,7 +94,7 @@ __device__ __forceinline__ void acc_store_h16(const f32x4 (&acc)[MTL][NTL], unsi
 #pragma unroll
         for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) Hs[(mt * 16 + 4 * kq + i) * ldh + c] = f2h(act_apply(acc[mt][nt][i] + bv, act));
+            for (int i = 0; i < 4; ++i) Hs[(mt * 16 + 4 * kq + i) * ldh + c] = f2h(h_act(acc[mt][nt][i] + bv, act));
     }
 }
 
@@ -357,16 +367,16 @@ __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
         }
     }
     __syncthreads();
-    for (int rr = 0; rr < 8; ++rr) {                           // softmax (fp32) -> fp16 probabilities
-        const float* prow = Ps + (wave * 8 + rr) * ldp;
+    for (int rr = 0; rr < 8; ++rr) {                           // softmax (fp32) -> fp16 probabilities; one exp per element
+        float* prow = Ps + (wave * 8 + rr) * ldp;
         unsigned short* hrow = Ph + (wave * 8 + rr) * ldph;
         float mx = -INFINITY;
         for (int c = lane; c < a.Sp; c += 64) mx = fmaxf(mx, prow[c]);
         mx = wave_max(mx);
         float sum = 0.f;
-        for (int c = lane; c < a.Sp; c += 64) sum += expf(prow[c] - mx);
-        const float inv = 1.f / wave_sum(sum);
-        for (int c = lane; c < a.Sp; c += 64) hrow[c] = f2h(expf(prow[c] - mx) * inv);
+        for (int c = lane; c < a.Sp; c += 64) { const float e = h_exp(prow[c] - mx); prow[c] = e; sum += e; }
+        const float inv = __builtin_amdgcn_rcpf(wave_sum(sum));
+        for (int c = lane; c < a.Sp; c += 64) hrow[c] = f2h(prow[c] * inv);
     }
     __syncthreads();
     {   // O = P V : contraction over keys, V^T rows are the B operand
