@@ -639,7 +639,13 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     if (epi) st4(keep, xr);
 
     // ---- prologue: constants, layer 0 operands, first input vector, first DEN_R chunks
-    int row = A.trow_per_sample ? A.trow[b] : A.trow[0];
+    // per-step scalars (table row, scheduler coefficients) through the constant address space: scalar loads, which do
+    // not queue behind (and whose waits do not drain) the vector-memory weight ring
+    typedef const __attribute__((address_space(4))) int32_t* CI32;
+    typedef const __attribute__((address_space(4))) float* CF32;
+    const CI32 trow_c = (CI32)(uintptr_t)A.trow;
+    const CF32 coef_c = (CF32)(uintptr_t)A.coef;
+    int row = A.trow_per_sample ? trow_c[b] : trow_c[0];
     {
         for (int i = tid0; i < 192; i += DEN_THREADS)
             st4(CONSTV + 4 * i, i < 64 ? ld4(vp + lay->pe0 + 4 * i) : (i < 128 ? ld4(vp + lay->fnw + 4 * (i - 64)) : ld4(vp + lay->fnb + 4 * (i - 128))));
@@ -665,7 +671,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
         if (step == 3) DEN_DBG(2);
         // table row of the NEXT step (the last layer stages layer 0 of the next step)
         const int step_next = step + 1 < A.steps ? step + 1 : step;
-        const int row_next = A.trow_per_sample ? row : A.trow[step_next];
+        const int row_next = A.trow_per_sample ? row : trow_c[step_next];
 #pragma unroll 1
         for (int l = 0; l < SEEME_DEN_NL; ++l) {
             const DenLayerOff* __restrict__ L = &lay->L[l];
@@ -914,7 +920,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                     if (epi) st4(keep, e);
                 } else if (epi) {
                     // ---- scheduler.step (mld.py:495-497; scalars prepared by seeme_amd/schedulers.py)
-                    const float* __restrict__ c = A.coef + (size_t)step * 8;
+                    const CF32 c = coef_c + (size_t)step * 8;
                     const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], clip = c[6], ptype = c[7];
                     float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (A.noise != nullptr) nz = ld4(A.noise + ((size_t)step * A.B + bl) * 256 + 4 * lane);
