@@ -258,7 +258,7 @@ static int launch_linear_h(const LinearHArgs& ha, hipStream_t st) {
 __global__ __launch_bounds__(512) void k_qkv_h(const LinearHArgs ha) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const SeemeLinearArgs& a = ha.k.a;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
+    const int tid = threadIdx.x, wave = tid >> 6;
     const int mh = wave >> 2, nq = wave & 3;
     constexpr int LDH = 256 + HPAD;
     unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);            // [128][272] fp16 operand tile, later the output tile
