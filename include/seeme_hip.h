@@ -276,13 +276,20 @@ int seeme_pointnet_encode(const SeemePointnetWeights* w, const float* points, in
                           void* workspace, size_t ws_bytes, void* stream);
 
 /* bf16-MFMA variant (fp32 accumulation): the same weights as bf16 copies packed in MFMA fragment order,
- * Wp[((n/16) * (K/32) + k/32) * 64 + lane][8] = W[16*(n/16) + (lane&15)][32*(k/32) + 8*(lane>>4) .. +7];
- * one fused kernel per ResnetBlockFC on 128-point tiles, max-pool folded into the epilogue.  Results differ
- * from the fp32 path by bf16 rounding of weights and activations (tolerance stated in the tests). */
+ * Wp[((t * (K/32) + k/32) * 64 + lane][8] = W[row(t, lane&15)][32*(k/32) + 8*(lane>>4) .. +7] for n-tile t, with
+ * the rows of an n-tile interleaved so that a lane of the kernel owns 16 consecutive output features:
+ * row(t, q) = 64*(t/4) + 16*(q/4) + 4*(t%4) + q%4.
+ * One fused persistent kernel per ResnetBlockFC on 128-point tiles, max-pool folded into the epilogue.  Results
+ * differ from the fp32 path by bf16 rounding of weights and activations (tolerance stated in the tests). */
 typedef struct {
     const uint16_t* fc0[4];     /* block_i.fc_0.weight   [256,512] packed */
     const uint16_t* fc1[4];     /* block_i.fc_1.weight   [256,256] packed */
-    const uint16_t* sc[4];      /* block_i.shortcut.weight [256,512] packed */
+    const uint16_t* sc[4];      /* block_i.shortcut.weight [256,512] packed (sc[0] unused: see sc3) */
+    const uint16_t* posf;       /* fc_pos_0 (weight [512,3], bias) as split-bf16 operands of v_mfma_f32_16x16x16_bf16,
+                                 * w = hi + lo: [32 n-tiles][64 lanes][4], lane = 16*kq + q for column 16*t + q:
+                                 * kq 0: whx why whz whx | kq 1: why whz wlx wly | kq 2: wlz bh bl 0 | kq 3: 0 */
+    const float* sc3;           /* block_0.shortcut folded through fc_pos_0 (both linear, no bias: respointnet.py:35,84,93):
+                                 * [256][4] fp32 = ( Ws Wp | Ws bp ) */
 } SeemePointnetBf16;
 size_t seeme_pointnet_bf16_workspace_bytes(int B, int P);
 int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const SeemePointnetBf16* wb, const float* points,

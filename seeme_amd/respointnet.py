@@ -58,16 +58,33 @@ class ResnetPointnet(nn.Module):
         w.fcc_w, w.fcc_b = L.ptr(self.fc_c.weight), L.ptr(self.fc_c.bias)
         with torch.no_grad():
             bf = [getattr(self, f"block_{i}") for i in range(4)]
+            # rows of n-tile t interleaved so that a kernel lane owns 16 consecutive features (include/seeme_hip.h)
+            tt, qq = torch.meshgrid(torch.arange(16), torch.arange(16), indexing="ij")
+            perm = (64 * (tt // 4) + 16 * (qq // 4) + 4 * (tt % 4) + qq % 4).reshape(-1).to(posw.device)
             def pack(W):   # [N,K] -> MFMA fragment order [N/16][K/32][kq=4][r=16][8] (1 KiB per wave-load)
                 N, K = W.shape
-                return W.to(torch.bfloat16).view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+                return W[perm].to(torch.bfloat16).view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
             fc0 = [pack(b.fc_0.weight) for b in bf]
             fc1 = [pack(b.fc_1.weight) for b in bf]
             sc = [pack(b.shortcut.weight) for b in bf]
+            # block_0's shortcut acts on fc_pos_0(p): two linear maps, folded in fp64 to a 3 -> 256 map
+            ws0 = bf[0].shortcut.weight.double()
+            sc3 = torch.cat([ws0 @ self.fc_pos_0.weight.double(), (ws0 @ self.fc_pos_0.bias.double())[:, None]], dim=1).float().contiguous()
+            # fc_pos_0 as split-bf16 matrix-core operands (include/seeme_hip.h: SeemePointnetBf16.posf)
+            pw, pbias = self.fc_pos_0.weight.float(), self.fc_pos_0.bias.float()
+            wh, bh = pw.to(torch.bfloat16), pbias.to(torch.bfloat16)
+            wl, bl = (pw - wh.float()).to(torch.bfloat16), (pbias - bh.float()).to(torch.bfloat16)
+            zz = torch.zeros_like(bh)
+            frag = torch.stack([torch.stack([wh[:, 0], wh[:, 1], wh[:, 2], wh[:, 0]], -1),
+                                torch.stack([wh[:, 1], wh[:, 2], wl[:, 0], wl[:, 1]], -1),
+                                torch.stack([wl[:, 2], bh, bl, zz], -1),
+                                torch.stack([zz, zz, zz, zz], -1)], dim=1)             # [512, kq, 4]
+            posf = frag.view(32, 16, 4, 4).permute(0, 2, 1, 3).contiguous()            # [n-tile][kq][q][4]
         wb = L.PointnetBf16()
         for i in range(4):
             wb.fc0[i], wb.fc1[i], wb.sc[i] = fc0[i].data_ptr(), fc1[i].data_ptr(), sc[i].data_ptr()
-        self._wcache = (fpnt, w, (posw, fc0, fc1, sc), wb)
+        wb.sc3, wb.posf = sc3.data_ptr(), posf.data_ptr()
+        self._wcache = (fpnt, w, (posw, fc0, fc1, sc, sc3, posf), wb)
         return w
 
     def forward(self, p: torch.Tensor) -> torch.Tensor:
