@@ -432,8 +432,37 @@ extern "C" size_t seeme_pointnet_bf16_workspace_bytes(int B, int P) {
     return M * PN_H * 2 * sizeof(unsigned short) + (size_t)B * PN_H * 6 * sizeof(float) + 256;
 }
 
-static int small_lin(hipStream_t st, const float* A, const float* W, int ldw, float* Y, int M, int pre_act) {
-    return seeme_linear_simple(st, A, PN_H, W, ldw, nullptr, Y, PN_H, M, PN_H, PN_H, SEEME_ACT_NONE, pre_act, nullptr, nullptr);
+// The small fp32 maps of pooled vectors that sit on the dependency chain between block kernels, two 256-output maps
+// per launch: the pooled halves of the next block (v0 = W0[:, 256:] relu(pool), vs = Ws[:, 256:] pool) and the final
+// fc_c(relu(pool)) as its two row halves.  grid (scene, 4): a workgroup owns 128 of the 512 outputs, 4 lanes per
+// output (a wave instruction reads 16 rows x 64 contiguous bytes), pooled vector from LDS.
+struct PnRowsArgs {
+    const float* pool;                      // [B,256]
+    const float* w[2]; const float* bias[2];   // row-major, row stride ldw floats, columns [col0, col0 + 256); bias may be NULL
+    float* y[2]; int ldy;                   // y[m][b * ldy + f]
+    int ldw, col0, relu[2];
+};
+__global__ __launch_bounds__(512) void k_pn_rows(const PnRowsArgs a) {
+    __shared__ __attribute__((aligned(16))) float sp[PN_H];
+    const int tid = threadIdx.x, b = blockIdx.x, which = blockIdx.y >> 1, sub = tid & 3;
+    const int f = (blockIdx.y & 1) * 128 + (tid >> 2);
+    if (tid < PN_H) {
+        const float p = a.pool[(size_t)b * PN_H + tid];
+        sp[tid] = a.relu[which] ? fmaxf(p, 0.f) : p;
+    }
+    __syncthreads();
+    const float4* row = reinterpret_cast<const float4*>(a.w[which] + (size_t)f * a.ldw + a.col0);
+    const float4* p4 = reinterpret_cast<const float4*>(sp);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < PN_H / 16; ++it) {
+        const float4 w = row[it * 4 + sub], p = p4[it * 4 + sub];
+        acc[0] += w.x * p.x; acc[1] += w.y * p.y; acc[2] += w.z * p.z; acc[3] += w.w * p.w;
+    }
+    float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+    if (sub == 0) a.y[which][(size_t)b * a.ldy + f] = v + (a.bias[which] != nullptr ? a.bias[which][f] : 0.f);
 }
 
 extern "C" int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const SeemePointnetBf16* wb, const float* points,
@@ -485,8 +514,11 @@ extern "C" int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const S
         } else {
             const float* pool_prev = pools + (size_t)(i - 1) * B * PN_H;
             // pooled halves in fp32: v0 = W0[:,256:] relu(pool), vs = Ws[:,256:] pool
-            if ((rc = small_lin(st, pool_prev, w->fc0_w[i] + PN_H, 512, v0, B, SEEME_ACT_RELU))) return rc;
-            if ((rc = small_lin(st, pool_prev, w->sc_w[i] + PN_H, 512, vs, B, SEEME_ACT_NONE))) return rc;
+            PnRowsArgs ra{};
+            ra.pool = pool_prev; ra.w[0] = w->fc0_w[i]; ra.w[1] = w->sc_w[i]; ra.y[0] = v0; ra.y[1] = vs; ra.ldy = PN_H;
+            ra.ldw = 512; ra.col0 = PN_H; ra.relu[0] = 1; ra.relu[1] = 0;
+            hipLaunchKernelGGL(k_pn_rows, dim3((unsigned)B, 4), dim3(512), 0, st, ra);
+            if ((rc = seeme_check_launch("k_pn_rows"))) return rc;
             a.x = cur; a.v0 = v0; a.vs = vs;
             hipLaunchKernelGGL((k_pn_block<false, MH_NEXT>), grid, dim3(256 * MH_NEXT), lds_next, st, a);
         }
@@ -494,6 +526,14 @@ extern "C" int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const S
         if (i > 0) { unsigned short* t = cur; cur = nxt; nxt = t; } else { cur = nxt; nxt = xa; }
     }
     // fc_c(relu(pool of block_3))
+    if (w->out_dim == 512) {
+        PnRowsArgs ra{};
+        ra.pool = pools + (size_t)3 * B * PN_H; ra.w[0] = w->fcc_w; ra.w[1] = w->fcc_w + (size_t)PN_H * PN_H;
+        ra.bias[0] = w->fcc_b; ra.bias[1] = w->fcc_b + PN_H; ra.y[0] = out; ra.y[1] = out + PN_H; ra.ldy = 512;
+        ra.ldw = PN_H; ra.col0 = 0; ra.relu[0] = ra.relu[1] = 1;
+        hipLaunchKernelGGL(k_pn_rows, dim3((unsigned)B, 4), dim3(512), 0, st, ra);
+        return seeme_check_launch("k_pn_rows");
+    }
     return seeme_linear_simple(st, pools + (size_t)3 * B * PN_H, PN_H, w->fcc_w, PN_H, w->fcc_b, out, w->out_dim, B, w->out_dim,
                                PN_H, SEEME_ACT_NONE, SEEME_ACT_RELU, nullptr, nullptr);
 }
