@@ -29,6 +29,8 @@ if hasattr(lib, "seeme_debug_pn_times"):
     f.argtypes = [C.c_void_p, C.c_int]
     buf = (C.c_ulonglong * 32)()
     L.check(f(buf, 32))
+    tt = np.array(buf[16:20], dtype=np.float64)
+    print("cycles per tile between tiles 3/13/23/33:", np.diff(tt) / 10)
     t = np.array(buf[:10], dtype=np.float64)
     names = ["land tile in LDS + barrier", "fc_0 gemm", "barrier", "hidden write + barrier", "fc_1 gemm", "shortcut gemm",
              "issue next tile", "epilogue from registers", "barrier"]

@@ -123,6 +123,9 @@ struct PnBlockArgs {
     int P, tiles_x, n_tiles;                // tiles per scene, tiles in all
 };
 
+// fmaxf() canonicalises both operands first (3 instructions); the values here are never signalling NaNs
+// (as v_med3_f32 with +inf: one instruction the compiler schedules and hazard-checks itself)
+__device__ __forceinline__ float pn_max(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
 typedef float pn_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 pn_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {   // one v_cvt_pk_bf16_f32
@@ -169,12 +172,7 @@ __global__ __launch_bounds__(256 * MH, 2) void k_pn_block(const PnBlockArgs a) {
     // ---- prefetch registers of the next tile
     constexpr int NIT = FIRST ? 1 : MT * (PN_H / 8) / NTHR;   // 8 row segments of 16 B per thread
     pn_u32x4 pf[NIT];
-    float pf_b0 = 0.f, pf_b1 = 0.f, pf_v0 = 0.f, pf_vs = 0.f, pf_pt = 0.f;
-    const unsigned n_scenes = (unsigned)(a.n_tiles / a.tiles_x);
-    const __amdgpu_buffer_rsrc_t rb0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.b0), 0, PN_H * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.b1), 0, PN_H * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FIRST ? a.b0 : a.v0), 0, (FIRST ? 1u : n_scenes) * PN_H * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rvs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FIRST ? a.b1 : a.vs), 0, (FIRST ? 1u : n_scenes) * PN_H * 4, 0x00020000);
+    float pf_pt = 0.f;
     auto issue = [&](int tn) {
         const int sc = tn / a.tiles_x, q0 = (tn - sc * a.tiles_x) * MT, rv = min(MT, a.P - q0);
         if (FIRST) {
@@ -191,12 +189,6 @@ __global__ __launch_bounds__(256 * MH, 2) void k_pn_block(const PnBlockArgs a) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 pf[it] = __builtin_amdgcn_raw_buffer_load_b128(rt, (unsigned)tid * 16u, (unsigned)(it * NTHR * 16), 0);
-            const unsigned vo = (unsigned)(tid & (PN_H - 1)) * 4u, so = (unsigned)sc * (PN_H * 4u);
-            // (summed when the tile lands: an add here would be a wait for the tile's loads right after their issue)
-            pf_b0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb0, vo, 0, 0));
-            pf_v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv0, vo, so, 0));
-            pf_b1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb1, vo, 0, 0));
-            pf_vs = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvs, vo, so, 0));
         }
     };
 
@@ -214,7 +206,7 @@ __global__ __launch_bounds__(256 * MH, 2) void k_pn_block(const PnBlockArgs a) {
                 const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wf, pfr[mt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 // lane (r, kq) holds columns 64 nq + 16 n4 + 4 kq .. +3 (of the half) of point row0 + 16 mt + r
                 *reinterpret_cast<uint2*>(xp + mt * 16 * LDA + n4 * 16) =
-                    make_uint2(pack_bf16x2(fmaxf(c[0], 0.f), fmaxf(c[1], 0.f)), pack_bf16x2(fmaxf(c[2], 0.f), fmaxf(c[3], 0.f)));
+                    make_uint2(pack_bf16x2(pn_max(c[0], 0.f), pn_max(c[1], 0.f)), pack_bf16x2(pn_max(c[2], 0.f), pn_max(c[3], 0.f)));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -226,7 +218,7 @@ __global__ __launch_bounds__(256 * MH, 2) void k_pn_block(const PnBlockArgs a) {
     __shared__ __attribute__((aligned(16))) float smax[MH][PN_H];
     const int t0 = (int)(((long long)blockIdx.x * a.n_tiles) / gridDim.x), t1 = (int)(((long long)(blockIdx.x + 1) * a.n_tiles) / gridDim.x);
     float run_max = -INFINITY;
-    int prev_scene = -1;
+    int prev_scene = -1, bias_scene = -1;
     // the weight stream: fc_0 | fc_1 | shortcut per tile, PN_PF k-blocks ahead across GEMM and tile boundaries
     const PnMat<16> m0(a.w0, nq * 4), ms(FIRST ? a.w0 : a.ws, nq * 4);
     const PnMat<PN_H / 32> m1(a.w1, nq * 4);
@@ -236,6 +228,10 @@ __global__ __launch_bounds__(256 * MH, 2) void k_pn_block(const PnBlockArgs a) {
         const int scene = t / a.tiles_x, p0 = (t - scene * a.tiles_x) * MT;
         const int rows_valid = min(MT, a.P - p0);
         PN_DBG(0);
+#ifdef PN_DBG_TIMES
+        if (FIRST == (PN_DBG_FIRST != 0) && a.out != nullptr && blockIdx.x == 40 && threadIdx.x == 0 && (t - t0) % 10 == 3 && (t - t0) / 10 < 4)
+            pn_dbg_times[16 + (t - t0) / 10] = __builtin_readcyclecounter();     // tiles 3, 13, 23, 33: cycles per tile in the steady state
+#endif
         // ---- land the prefetched tile in LDS
         if (FIRST) {
             if (tid < MT * 3) spts[tid] = pf_pt;
@@ -262,7 +258,18 @@ __global__ __launch_bounds__(256 * MH, 2) void k_pn_block(const PnBlockArgs a) {
                 *reinterpret_cast<uint4*>(T0 + row * LDA + c8) = make_uint4(pf[it].x, pf[it].y, pf[it].z, pf[it].w);
                 *reinterpret_cast<uint4*>(T1 + row * LDA + c8) = make_uint4(relu2(pf[it].x), relu2(pf[it].y), relu2(pf[it].z), relu2(pf[it].w));
             }
-            if (tid < PN_H) { sb0[tid] = pf_b0 + pf_v0; sb1[tid] = pf_b1 + pf_vs; }
+            // biases + pooled halves of this tile's scene: re-read only when the scene changes (tiles are scene-major;
+            // as prefetch registers they were spilled right after their loads -- a vmcnt(0) under the tile prefetch)
+            if (scene != bias_scene) {
+                if (wave < 4) {
+                    int ln;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+                    const int c = wave * 64 + ln;
+                    sb0[c] = a.b0[c] + a.v0[(size_t)scene * PN_H + c];
+                    sb1[c] = a.b1[c] + a.vs[(size_t)scene * PN_H + c];
+                }
+                bias_scene = scene;
+            }
         }
         __syncthreads();
         PN_DBG(1);
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256 * MH, 2) void k_pn_block(const PnBlockArgs a) {
             int ln;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
             const int tt = wave * 64 + ln;
-            run_max = fmaxf(run_max, fmaxf(smax[0][tt], smax[MH - 1][tt]));
+            run_max = pn_max(run_max, pn_max(smax[0][tt], smax[MH - 1][tt]));
             if (scene != prev_scene) {
                 atomic_max_f32(a.pool + (size_t)prev_scene * PN_H + tt, run_max);
                 run_max = -INFINITY;
@@ -310,8 +317,8 @@ __global__ __launch_bounds__(256 * MH, 2) void k_pn_block(const PnBlockArgs a) {
                 unsigned w[8];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    w[2 * nt] = pack_bf16x2(fmaxf(acc[mt][nt][0] + bv[4 * nt], 0.f), fmaxf(acc[mt][nt][1] + bv[4 * nt + 1], 0.f));
-                    w[2 * nt + 1] = pack_bf16x2(fmaxf(acc[mt][nt][2] + bv[4 * nt + 2], 0.f), fmaxf(acc[mt][nt][3] + bv[4 * nt + 3], 0.f));
+                    w[2 * nt] = pack_bf16x2(pn_max(acc[mt][nt][0] + bv[4 * nt], 0.f), pn_max(acc[mt][nt][1] + bv[4 * nt + 1], 0.f));
+                    w[2 * nt + 1] = pack_bf16x2(pn_max(acc[mt][nt][2] + bv[4 * nt + 2], 0.f), pn_max(acc[mt][nt][3] + bv[4 * nt + 3], 0.f));
                 }
                 unsigned short* hp = Hs + (row0 + mt * 16 + r) * LDH + fbase;
                 *reinterpret_cast<uint4*>(hp) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -347,13 +354,16 @@ __global__ __launch_bounds__(256 * MH, 2) void k_pn_block(const PnBlockArgs a) {
             }
             const bool has_out = a.out != nullptr;
             const unsigned vo0 = (unsigned)((row0 + r) * PN_H + fbase) * 2u;
+            const int row0r = row0 + r;
             // rows past the tile's valid bytes are dropped by the buffer bounds check
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
                 has_out ? a.out + ((size_t)scene * a.P + p0) * PN_H : nullptr, 0, has_out ? rows_valid * PN_H * 2 : 0, 0x00020000);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int row = row0 + mt * 16 + r;
-                const bool valid = row < rows_valid;
+                int rvm = rows_valid - mt * 16;                // one lane value (row0 + r) for all row tiles (see vo0):
+                asm volatile("" : "+s"(rvm));                  // the scalar side carries mt, kept from being re-associated
+                const bool valid = row0r < rvm;
                 float v[16];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(256 * MH, 2) void k_pn_block(const PnBlockArgs a) {
                 }
                 if (valid) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) mx[j] = fmaxf(mx[j], v[j]);
+                    for (int j = 0; j < 16; ++j) mx[j] = pn_max(mx[j], v[j]);
                 }
                 __builtin_amdgcn_sched_barrier(0);             // one row tile at a time: the ring and the prefetched tile stay in registers
             }
@@ -393,23 +403,27 @@ __global__ __launch_bounds__(256 * MH, 2) void k_pn_block(const PnBlockArgs a) {
             float a8[8], a4[4], a2[2], a1;
             const bool b3 = r & 8, b2 = r & 4, b1 = r & 2, b0 = r & 1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a8[j] = fmaxf(b3 ? mx[j + 8] : mx[j], xch(b3 ? mx[j] : mx[j + 8], 0));
+            for (int j = 0; j < 8; ++j) a8[j] = pn_max(b3 ? mx[j + 8] : mx[j], xch(b3 ? mx[j] : mx[j + 8], 0));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a4[j] = fmaxf(b2 ? a8[j + 4] : a8[j], xch(b2 ? a8[j] : a8[j + 4], 1));
+            for (int j = 0; j < 4; ++j) a4[j] = pn_max(b2 ? a8[j + 4] : a8[j], xch(b2 ? a8[j] : a8[j + 4], 1));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) a2[j] = fmaxf(b1 ? a4[j + 2] : a4[j], xch(b1 ? a4[j] : a4[j + 2], 2));
-            a1 = fmaxf(b0 ? a2[1] : a2[0], xch(b0 ? a2[0] : a2[1], 3));
+            for (int j = 0; j < 2; ++j) a2[j] = pn_max(b1 ? a4[j + 2] : a4[j], xch(b1 ? a4[j] : a4[j + 2], 2));
+            a1 = pn_max(b0 ? a2[1] : a2[0], xch(b0 ? a2[0] : a2[1], 3));
             // the next block consumes the pooled vector through bf16 activations of equal rounding: pool the value that
             // is actually stored (rounding is monotone, so the max is rounded once)
             if (has_out) a1 = __uint_as_float(pack_bf16x2(a1, 0.f) << 16);
-            smax[mh][nq * 64 + lane] = a1;                      // feature 64 nq + 16 kq + r
+            {
+                int ln;                                        // formed here: see the running-max fold above
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+                smax[mh][nq * 64 + ln] = a1;                   // feature 64 nq + 16 kq + r
+            }
         }
         PN_DBG(8);
         __syncthreads();                                       // tiles, biases and points of this tile are dead
         PN_DBG(9);
     }
     if (tid < PN_H && prev_scene >= 0) {
-        run_max = fmaxf(run_max, fmaxf(smax[0][tid], smax[MH - 1][tid]));
+        run_max = pn_max(run_max, pn_max(smax[0][tid], smax[MH - 1][tid]));
         atomic_max_f32(a.pool + (size_t)prev_scene * PN_H + tid, run_max);
     }
 }
