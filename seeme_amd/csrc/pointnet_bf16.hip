@@ -2,22 +2,24 @@
 // bf16-MFMA kernels: the one part of the path with GEMMs big enough for the matrix cores
 // (M = B x 20 000 points).
 //
-// One workgroup (4 waves) owns a tile of 128 points of one scene and runs a whole ResnetBlockFC on it:
+// A persistent 4-wave workgroup (two per CU) walks 64-point tiles of the scenes and runs a whole ResnetBlockFC on each:
 //     hid = relu( W0[:, :256] relu(x) + W0[:, 256:] relu(pool) + b0 )          fc_0
 //     out =       Ws[:, :256] x       + Ws[:, 256:] pool
 //               + W1 hid + b1                                                   shortcut + fc_1, ONE accumulator
 // The point features stay in LDS as bf16 (raw and relu'd copies), the hidden tile overwrites the relu'd copy,
-// weights stream from L2 as bf16 rows (each wave reads its own 16-byte B fragments), accumulation is fp32
-// (v_mfma_f32_16x16x32_bf16).  The per-scene max-pool of the block output is folded into the epilogue
-// (tile max -> one atomic per column), so no pass over the [M,256] tensor is spent on pooling; activations
-// travel between blocks as bf16 (half the HBM bytes).  The pooled halves are per-scene fp32 vectors
-//  produced by the small fp32 linear kernel.
+// weights stream from L2 as fragment-packed bf16 through a register ring that runs across GEMMs and tiles,
+// accumulation is fp32 (v_mfma_f32_16x16x32_bf16, weight fragment as the A operand so that a lane owns 16 consecutive
+// features of one point).  Hidden tile, block output and the per-scene max-pool come straight from the accumulators;
+// the pool reaches memory through one atomic per feature per scene change; activations travel between blocks as bf16
+// (half the HBM bytes).  The pooled halves are per-scene fp32 vectors from k_pn_rows.  block_0
+// generates its input fc_pos_0(points) on the matrix cores (split-bf16 operands) and evaluates its shortcut, folded
+// through fc_pos_0 to a 3 -> 256 map, in the epilogue.  DESIGN.md section 5.2 has the measurements behind each choice.
 #include "common.hpp"
 #include "api_util.hpp"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef PN_MH_FIRST
-#define PN_MH_FIRST 1      // first block, same meaning
+#define PN_MH_FIRST 1      // first block: 64-point row groups per workgroup (see PN_MH_NEXT)
 #endif
 #ifndef PN_MH_NEXT
 #define PN_MH_NEXT 1       // later blocks: 64-point row groups per workgroup (1: 4 waves, two workgroups per CU; 2: 8 waves, one)
