@@ -511,6 +511,28 @@ def test_pointnet_bf16_vs_fp32(dev):
     assert rel_err(got.cpu().numpy(), O.pointnet_forward(P, pts.cpu().numpy())) < 3e-2
 
 
+def test_pointnet_bf16_tile_walk(dev):
+    """The persistent block kernels give every workgroup a contiguous range of 64-point tiles that may span scene
+    boundaries, with the column max carried in registers between tiles.  Per-point arithmetic and the max are
+    independent of that partition, so a scene encoded alone (one tile per workgroup) and inside a large batch (several
+    tiles per workgroup, scene changes inside a range, partial last tiles) must agree BIT-exactly; the fp32 path bounds
+    the values themselves."""
+    from seeme_amd.respointnet import ResnetPointnet
+    pn = load_recipe_(ResnetPointnet(512, 256)).to(dev).eval()
+    rng = np.random.default_rng(11)
+    for B, P, probe in ((40, 1000, (0, 17, 39)), (6, 20000, (0, 3, 5)), (700, 50, (0, 333, 699)), (2, 64, (1,))):
+        pts = torch.from_numpy(rng.uniform(-3, 3, (B, P, 3)).astype(np.float32)).to(dev)
+        pn.precision = "bf16"
+        got = pn(pts)
+        assert torch.isfinite(got).all()
+        for i in probe:
+            alone = pn(pts[i:i + 1].contiguous())
+            assert torch.equal(alone[0], got[i]), (B, P, i, float((alone[0] - got[i]).abs().max()))
+        pn.precision = "fp32"
+        ref = pn(pts[list(probe)].contiguous())
+        assert rel_err(got[list(probe)].cpu().numpy(), ref.cpu().numpy()) < 3e-2
+
+
 def test_vae_fp16_mfma_mode(dev):
     """Throughput mode of the VAE (fp16 MFMA operands, fp32 accumulation and residual stream): measured against the
     reference fixtures; bound 2e-2 of the output range (reported, not the 1e-4 parity gate)."""
