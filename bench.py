@@ -12,7 +12,7 @@ recipe (no checkpoint exists offline); data is synthetic N(0,1) of the named sha
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` (dominant kernel,
-timed with events on its own stream) and `cpu_baseline` (the numpy oracle on the host cores, N=1 only).
+timed with events on its own stream) and `cpu_baseline` (the PyTorch-CPU oracle on the host cores, N=1 only).
 """
 import argparse
 import json
@@ -97,27 +97,48 @@ def measured_traffic(weights, B, steps):
 
 
 def cpu_baseline(B, budget_s=12.0):
-    """The numpy oracle (a port of the reference CPU path, pinned to it by tests/golden) on this host."""
-    from oracle import mld_oracle as O
+    """The CPU oracle (oracle/mld_oracle_torch.py: a port of the reference CPU path on PyTorch-CPU fp32 -- the baseline
+    SURVEY.md section 8(d) names -- pinned to the reference by tests/golden) on this host, same pass as the GPU leg:
+    VAE encode -> 50-step DDIM -> VAE decode at the bench batch.  The thread count is picked by a short trial
+    (more threads than the box's CPU share only add contention) and reported as `cores`."""
+    from oracle import mld_oracle_torch as OT
     from seeme_amd import shapes
     from seeme_amd.weights_recipe import recipe_state_dict
-    Pv, Pd = recipe_state_dict(shapes.vae_shapes(NFEATS)), recipe_state_dict(shapes.denoiser_shapes())
+    Pv, Pd = OT.to_torch(recipe_state_dict(shapes.vae_shapes(NFEATS))), OT.to_torch(recipe_state_dict(shapes.denoiser_shapes()))
     rng = np.random.Generator(np.random.PCG64(1234))
-    Bc = min(B, 8)
-    motion = rng.standard_normal((Bc, T_FRAMES, NFEATS)).astype(np.float32)
-    lat = rng.standard_normal((Bc, 1, 256)).astype(np.float32)
+    Bc = min(B, 32)
+    motion = torch.from_numpy(rng.standard_normal((Bc, T_FRAMES, NFEATS)).astype(np.float32))
+    lat = torch.from_numpy(rng.standard_normal((Bc, 1, 256)).astype(np.float32))
     lengths = [T_FRAMES] * Bc
+
+    def one():
+        mu, _ = OT.vae_encode(Pv, motion, lengths)
+        z = OT.diffusion_reverse(Pd, mu.permute(1, 0, 2), lat, DDIM_STEPS)
+        OT.vae_decode(Pv, z, lengths)
+
+    prev = torch.get_num_threads()
+    ncpu = os.cpu_count() or 1
+    trials = {}
+    for th in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+        torch.set_num_threads(th)
+        one()                                             # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        one()
+        trials[th] = time.perf_counter() - t0
+    best = min(trials, key=trials.get)
+    torch.set_num_threads(best)
     n, t0 = 0, time.perf_counter()
     while True:
-        mu, _ = O.vae_encode(Pv, motion, lengths)
-        z = O.diffusion_reverse(Pd, np.transpose(mu, (1, 0, 2)), lat, DDIM_STEPS)
-        O.vae_decode(Pv, z, lengths)
+        one()
         n += Bc
         dt = time.perf_counter() - t0
         if dt > budget_s:
             break
-    return {"value": round(n / dt, 3), "unit": "seqs/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n} sequences (passes of B={Bc}, T=196, 50 DDIM steps) in {dt:.1f}s, numpy/OpenBLAS fp32 oracle"}
+    torch.set_num_threads(prev)
+    return {"value": round(n / dt, 3), "unit": "seqs/s", "cores": best, "kind": "port",
+            "sample": f"{n} sequences (passes of B={Bc}, T=196, 50 DDIM steps) in {dt:.1f}s, PyTorch-CPU fp32 oracle, "
+                      f"{best} threads of {ncpu} logical CPUs (trial s/pass: "
+                      + ", ".join(f"{k}t {v:.2f}" for k, v in trials.items()) + ")"}
 
 
 def main():

@@ -64,6 +64,32 @@ def test_ddim_loop_cfg():
     assert rel_err(out, g["out"]) < 2e-4
 
 
+# ----------------------------------------------------------------------------- the torch-on-CPU edition of the oracle
+def test_torch_oracle_matches_reference_fixtures():
+    """oracle/mld_oracle_torch.py (the cpu_baseline of bench.py) against the same reference-generated fixtures."""
+    import torch
+    from oracle import mld_oracle_torch as OT
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    for name, F in (("vae_F132_T24.npz", 132), ("vae_F75_T60.npz", 75)):
+        g = load_golden(name)
+        P = OT.to_torch(vae_params(F))
+        mu, std = OT.vae_encode(P, tt(g["features"]), g["lengths"].tolist())
+        assert rel_err(mu.numpy(), g["mu"]) < TOL and rel_err(std.numpy(), g["std"]) < TOL
+        assert rel_err(OT.vae_decode(P, tt(g["mu"]), g["lengths"].tolist()).numpy(), g["decoded"]) < TOL
+    Pd = OT.to_torch(den_params())
+    for N in (1, 2):
+        g = load_golden(f"denoiser_N{N}.npz")
+        for t in (981, 1):
+            assert rel_err(OT.denoiser_forward(Pd, tt(g["sample"]), t, tt(g["cond"])).numpy(), g[f"out_t{t}"]) < TOL
+        assert rel_err(OT.denoiser_forward(Pd, tt(g["sample"]), g["tvec"], tt(g["cond"])).numpy(), g["out_tvec"]) < TOL
+    g = load_golden("ddim50_N1_B3.npz")
+    out = OT.diffusion_reverse(Pd, tt(g["cond_bf"]), tt(g["latents"]), int(g["steps"]))
+    assert out.shape == g["out"].shape and rel_err(out.numpy(), g["out"]) < 2e-4
+    g = load_golden("ddim10_N2_B2_cfg.npz")
+    out = OT.diffusion_reverse(Pd, tt(g["cond_bf"]), tt(g["latents"]), int(g["steps"]), guidance_scale=float(g["guidance_scale"]))
+    assert rel_err(out.numpy(), g["out"]) < 2e-4
+
+
 def test_misc():
     g = load_golden("misc.npz")
     # sin/cos of arguments up to 999: one fp32 ulp of the frequency is 6e-5 in the argument
