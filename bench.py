@@ -117,14 +117,21 @@ def cpu_baseline(B, budget_s=12.0):
         OT.vae_decode(Pv, z, lengths)
 
     prev = torch.get_num_threads()
-    ncpu = os.cpu_count() or 1
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     trials = {}
-    for th in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+
+    def short():                                          # trial workload: the encode + 5 of the 50 steps
+        mu, _ = OT.vae_encode(Pv, motion, lengths)
+        OT.diffusion_reverse(Pd, mu.permute(1, 0, 2), lat, 5)
+
+    for th in sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)}):
         torch.set_num_threads(th)
-        one()                                             # warm-up (thread pool, allocator)
+        short()                                           # warm-up (thread pool, allocator)
         t0 = time.perf_counter()
-        one()
+        short()
         trials[th] = time.perf_counter() - t0
+        if trials[th] > 1.2 * min(trials.values()):       # past the box's CPU share more threads only add contention
+            break
     best = min(trials, key=trials.get)
     torch.set_num_threads(best)
     n, t0 = 0, time.perf_counter()
@@ -137,7 +144,7 @@ def cpu_baseline(B, budget_s=12.0):
     torch.set_num_threads(prev)
     return {"value": round(n / dt, 3), "unit": "seqs/s", "cores": best, "kind": "port",
             "sample": f"{n} sequences (passes of B={Bc}, T=196, 50 DDIM steps) in {dt:.1f}s, PyTorch-CPU fp32 oracle, "
-                      f"{best} threads of {ncpu} logical CPUs (trial s/pass: "
+                      f"{best} threads of {ncpu} usable logical CPUs (trial s: "
                       + ", ".join(f"{k}t {v:.2f}" for k, v in trials.items()) + ")"}
 
 
