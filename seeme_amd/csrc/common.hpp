@@ -199,6 +199,24 @@ __device__ __forceinline__ void acc_store_lds(const f32x4 (&acc)[MTL][NTL], floa
 }
 
 // LayerNorm of one 256-wide row held 4 floats per lane by a full wave (two-pass, torch semantics).
+// LayerNorm parameters of this lane's 4 columns, loaded once per kernel phase: inside a row loop that also stores
+// to global memory the compiler re-reads them per row, and every row then waits on an L2 round trip.
+struct LnParams { float4 w, b; };
+__device__ __forceinline__ LnParams ln_params256(const float* __restrict__ w, const float* __restrict__ b) {
+    const int lane = threadIdx.x & 63;
+    LnParams p;
+    p.w = w != nullptr ? *reinterpret_cast<const float4*>(w + lane * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    p.b = b != nullptr ? *reinterpret_cast<const float4*>(b + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return p;
+}
+__device__ __forceinline__ float4 wave_layernorm256(float4 v, const LnParams& p, float eps) {
+    float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+    float4 c = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+    float var = wave_sum(c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) * (1.f / 256.f);
+    float rs = 1.f / sqrtf(var + eps);
+    return make_float4(c.x * rs * p.w.x + p.b.x, c.y * rs * p.w.y + p.b.y, c.z * rs * p.w.z + p.b.z,
+                       c.w * rs * p.w.w + p.b.w);
+}
 __device__ __forceinline__ float4 wave_layernorm256(float4 v, const float* __restrict__ w,
                                                     const float* __restrict__ b, float eps) {
     const int lane = threadIdx.x & 63;

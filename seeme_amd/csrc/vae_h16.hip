@@ -25,45 +25,51 @@ __device__ __forceinline__ float h_gelu(float x) {
 }
 __device__ __forceinline__ float h_act(float v, int act) { return act == SEEME_ACT_GELU ? h_gelu(v) : act_apply(v, act); }
 
+#ifndef H16_PF
+#define H16_PF 2      // k-blocks of weight fragments in flight in the tile GEMMs (measured: 4 is no faster)
+#endif
 template <int MTL, int NTL, int PF, typename LoadB>
 __device__ __forceinline__ void tile_gemm_h16(const unsigned short* __restrict__ As, int lda, int K32, LoadB loadb,
                                               f32x4 (&acc)[MTL][NTL]) {
+    static_assert(PF % 2 == 0, "A-fragment ping-pong follows the slot parity");
     const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
     const unsigned short* ap = As + r * lda + 8 * kq;
+    // PF k-blocks of B fragments in flight; a slot is re-filled right after the MFMAs that read it.  The scheduler is
+    // fenced per k-block: left alone it sinks the re-fills to just before their use (a vmcnt(0) per k-block) and the
+    // pipeline collapses -- these tiles are latency-bound, the depth of this pipeline is their speed.
     uint4 br[PF][NTL];
 #pragma unroll
     for (int u = 0; u < PF; ++u)
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) br[u][nt] = loadb(nt, u < K32 ? u : K32 - 1);
-    uint4 an[MTL];
+    uint4 ab[2][MTL];
 #pragma unroll
-    for (int mt = 0; mt < MTL; ++mt) an[mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda);
+    for (int mt = 0; mt < MTL; ++mt) ab[0][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda);
     for (int kb0 = 0; kb0 < K32; kb0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int kb = kb0 + u;
             if (kb < K32) {
-                h16x8 b[NTL], a[MTL];
-#pragma unroll
-                for (int nt = 0; nt < NTL; ++nt) b[nt] = __builtin_bit_cast(h16x8, br[u][nt]);
-#pragma unroll
-                for (int mt = 0; mt < MTL; ++mt) a[mt] = __builtin_bit_cast(h16x8, an[mt]);
-                const int kn = (kb + PF < K32) ? kb + PF : K32 - 1;
-#pragma unroll
-                for (int nt = 0; nt < NTL; ++nt) br[u][nt] = loadb(nt, kn);
                 const int ka = (kb + 1 < K32) ? kb + 1 : kb;
 #pragma unroll
-                for (int mt = 0; mt < MTL; ++mt) an[mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda + ka * 32);
+                for (int mt = 0; mt < MTL; ++mt) ab[(u + 1) & 1][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda + ka * 32);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NTL; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, ab[u & 1][mt]), __builtin_bit_cast(h16x8, br[u][nt]), acc[mt][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb + PF < K32) {
+#pragma unroll
+                    for (int nt = 0; nt < NTL; ++nt) br[u][nt] = loadb(nt, kb + PF);
+                }
             }
         }
     }
 }
 // B fragments from fragment-packed weights: Wp[(ntile*kstride + kb)*64 + lane]; n-tiles clamped to ntiles-1
-template <int MTL, int NTL, int PF = 2>
+template <int MTL, int NTL, int PF = H16_PF>
 __device__ __forceinline__ void gemm_packed(const unsigned short* As, int lda, const uint4* __restrict__ Wp, int kstride,
                                             int ntile0, int ntiles, int K32, f32x4 (&acc)[MTL][NTL]) {
     const int lane = threadIdx.x & 63;
@@ -73,7 +79,7 @@ __device__ __forceinline__ void gemm_packed(const unsigned short* As, int lda, c
     }, acc);
 }
 // B fragments from a row-major fp16 matrix Bm[n][k] (rows clamped to n_valid-1)
-template <int MTL, int NTL, int PF = 2>
+template <int MTL, int NTL, int PF = H16_PF>
 __device__ __forceinline__ void gemm_rows(const unsigned short* As, int lda, const unsigned short* __restrict__ Bm, int ldb,
                                           int n0, int n_valid, int K32, f32x4 (&acc)[MTL][NTL]) {
     const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
@@ -127,20 +133,37 @@ __global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
     const int m0 = blockIdx.x * TILE_M, cn0 = blockIdx.y * CH_N;
 
     if (fast) {   // float4 in, 4 halves out, no fp32 staging tile
-        const int Kp4 = Kp >> 2, K4 = a.K >> 2;
-        for (int idx = tid; idx < TILE_M * Kp4; idx += 256) {
-            const int row = idx / Kp4, c4 = idx - row * Kp4, m = m0 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < a.M && c4 < K4) {
-                int prow = m;
-                if (ka.seq_in > 0) prow = (m / ka.seq_in) * ka.in_stride + (m % ka.seq_in) + ka.in_off;
-                v = (4 * c4 < a.K1) ? *reinterpret_cast<const float4*>(a.A + (size_t)prow * a.lda + 4 * c4)
-                                    : *reinterpret_cast<const float4*>(a.A2 + (size_t)prow * a.lda2 + (4 * c4 - a.K1));
-                if (a.pre_act != SEEME_ACT_NONE)
-                    v = make_float4(act_apply(v.x, a.pre_act), act_apply(v.y, a.pre_act), act_apply(v.z, a.pre_act), act_apply(v.w, a.pre_act));
+        // Batches of 8 guarded loads per thread, ALL issued before the first is converted.  Written as
+        // "if (valid) v = load" per element the compiler emitted branch + load + vmcnt(0) per iteration: 8-16
+        // serialized memory round trips per tile, most of the time of these latency-bound kernels.  The guard is a
+        // select on the address (invalid lanes read the tile's first word) and on the value.
+        const int Kp4 = Kp >> 2, K4 = a.K >> 2, total = TILE_M * Kp4;
+        for (int base = 0; base < total; base += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = base + tid + j * 256, row = idx / Kp4, c4 = idx - row * Kp4, m = m0 + row;
+                const bool valid = idx < total && m < a.M && c4 < K4;
+                int prow = valid ? m : 0;
+                if (ka.seq_in > 0) prow = (prow / ka.seq_in) * ka.in_stride + (prow % ka.seq_in) + ka.in_off;
+                const bool first = 4 * c4 < a.K1 || a.A2 == nullptr;
+                const float* p = first ? a.A + (size_t)prow * a.lda + 4 * c4 : a.A2 + (size_t)prow * a.lda2 + (4 * c4 - a.K1);
+                v[j] = *reinterpret_cast<const float4*>(valid ? p : a.A);
+                if (!valid) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            const unsigned lo = (unsigned)f2h(v.x) | ((unsigned)f2h(v.y) << 16), hi = (unsigned)f2h(v.z) | ((unsigned)f2h(v.w) << 16);
-            *reinterpret_cast<uint2*>(Ah + row * lda_h + 4 * c4) = make_uint2(lo, hi);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = base + tid + j * 256, row = idx / Kp4, c4 = idx - row * Kp4;
+                if (idx < total) {
+                    float4 w = v[j];
+                    if (a.pre_act != SEEME_ACT_NONE)
+                        w = make_float4(act_apply(w.x, a.pre_act), act_apply(w.y, a.pre_act), act_apply(w.z, a.pre_act), act_apply(w.w, a.pre_act));
+                    if (!(m0 + row < a.M && c4 < K4)) w = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const unsigned lo = (unsigned)f2h(w.x) | ((unsigned)f2h(w.y) << 16), hi = (unsigned)f2h(w.z) | ((unsigned)f2h(w.w) << 16);
+                    *reinterpret_cast<uint2*>(Ah + row * lda_h + 4 * c4) = make_uint2(lo, hi);
+                }
+            }
         }
         __syncthreads();
     } else {
@@ -205,6 +228,25 @@ __global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
         return;
     }
     const bool vec_ok = ((a.ldy & 3) == 0) && ((a.N & 3) == 0);
+    // residual rows as float4, all 8 of the wave requested together (when rows are 16-byte aligned and whole)
+    const bool res_vec = a.res != nullptr && ((a.ldr & 3) == 0) && ((a.N & 3) == 0) && ((reinterpret_cast<size_t>(a.res) & 15) == 0);
+    const LnParams lp = ln_params256(a.ln_w, a.ln_b);
+    float4 rv[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        rv[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res_vec) {
+            const int m = m0 + wave * 8 + rr, mc = m < a.M ? m : 0, g = cn0 + lane * 4;
+            int orow = mc;
+            if (ka.seq_in > 0) orow = (mc / ka.seq_in) * ka.out_stride + (mc % ka.seq_in) + ka.out_off;
+            const size_t rrow = ka.res_mode == 1 ? (size_t)((mc % ka.seq_in) + ka.res_off)
+                              : ka.res_mode == 2 ? (size_t)(mc / ka.seq_in) : (size_t)orow;
+            rv[rr] = *reinterpret_cast<const float4*>(a.res + rrow * a.ldr + (g + 3 < a.N ? g : 0));
+            if (g + 3 >= a.N) rv[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
         const int row = wave * 8 + rr, m = m0 + row;
         if (m >= a.M) continue;
@@ -212,7 +254,9 @@ __global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
         if (ka.seq_in > 0) orow = (m / ka.seq_in) * ka.out_stride + (m % ka.seq_in) + ka.out_off;
         const int c = lane * 4, g = cn0 + c;
         float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + c);
-        if (a.res != nullptr) {
+        if (res_vec) {
+            v = make_float4(v.x + rv[rr].x, v.y + rv[rr].y, v.z + rv[rr].z, v.w + rv[rr].w);
+        } else if (a.res != nullptr) {
             const size_t rrow = ka.res_mode == 1 ? (size_t)((m % ka.seq_in) + ka.res_off)
                               : ka.res_mode == 2 ? (size_t)(m / ka.seq_in) : (size_t)orow;
             const float* rp = a.res + rrow * a.ldr + g;
@@ -221,7 +265,7 @@ __global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
             if (g + 2 < a.N) v.z += rp[2];
             if (g + 3 < a.N) v.w += rp[3];
         }
-        if (a.ln_w != nullptr) v = wave_layernorm256(v, a.ln_w, a.ln_b, a.eps);
+        if (a.ln_w != nullptr) v = wave_layernorm256(v, lp, a.eps);
         float* yp = a.Y + (size_t)orow * a.ldy + g;
         if (vec_ok && g + 3 < a.N) {
             *reinterpret_cast<float4*>(yp) = v;
@@ -269,9 +313,11 @@ __global__ __launch_bounds__(512) void k_qkv_h(const LinearHArgs ha) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 512, row = idx >> 6, c4 = idx & 63, m = m0 + row;
-            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < a.M) v[it] = *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + 4 * c4);
+            // guard as a select on address and value (see k_linear_h: a branch per load serialises the round trips)
+            v[it] = *reinterpret_cast<const float4*>(a.A + (m < a.M ? (size_t)m * a.lda + 4 * c4 : (size_t)0));
+            if (m >= a.M) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 512, row = idx >> 6, c4 = idx & 63;
@@ -396,15 +442,24 @@ __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
         acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, a.bo, 0, 256, SEEME_ACT_NONE);
     }
     __syncthreads();
-    for (int rr = 0; rr < 8; ++rr) {
-        const int row = wave * 8 + rr, s = q0 + row;
-        if (s >= a.q_rows) continue;
-        const size_t g = (base + s) * 256 + lane * 4;
-        float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + lane * 4);
-        const float4 x = *reinterpret_cast<const float4*>(a.res + g);
-        v = make_float4(v.x + x.x, v.y + x.y, v.z + x.z, v.w + x.w);
-        v = wave_layernorm256(v, a.ln_w, a.ln_b, a.eps);
-        *reinterpret_cast<float4*>(a.out + g) = v;
+    {   // residual rows and LayerNorm parameters requested together, then one pass of LN + store per row
+        const LnParams lp = ln_params256(a.ln_w, a.ln_b);
+        float4 xr[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int s = q0 + wave * 8 + rr;
+            xr[rr] = *reinterpret_cast<const float4*>(a.res + (base + (s < a.q_rows ? s : 0)) * 256 + lane * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr, s = q0 + row;
+            if (s >= a.q_rows) continue;
+            float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + lane * 4);
+            v = make_float4(v.x + xr[rr].x, v.y + xr[rr].y, v.z + xr[rr].z, v.w + xr[rr].w);
+            v = wave_layernorm256(v, lp, a.eps);
+            *reinterpret_cast<float4*>(a.out + (base + s) * 256 + lane * 4) = v;
+        }
     }
 }
 
@@ -440,22 +495,32 @@ __global__ __launch_bounds__(256) void k_ffn_block_h(const FfnHArgs a) {
     unsigned short* Xh = reinterpret_cast<unsigned short*>(Cs);            // ... whose head first holds the [32][272] fp16 A operand
                                                                            // (dead once the hidden layer is formed: 77 KB, 2 workgroups/CU)
     const int m0 = blockIdx.x * TILE_M;
-    for (int rr = 0; rr < 8; ++rr) {
-        const int row = wave * 8 + rr, m = m0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < a.M) {
-            const int seq = m / a.seq_rows;
-            const size_t prow = (size_t)seq * a.seq_stride + (m % a.seq_rows);
-            v = *reinterpret_cast<const float4*>(a.x + prow * 256 + lane * 4);
-            if (a.cvec != nullptr) {
-                const float4 c = *reinterpret_cast<const float4*>(a.cvec + (size_t)seq * a.cvec_ld + lane * 4);
-                v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
-                v = wave_layernorm256(v, a.lnc_w, a.lnc_b, a.eps);
-            }
+    {   // the wave's 8 rows (and their cross-attention vectors) are requested together, then normalised / converted
+        float4 xv[8], cv[8];
+        const LnParams lc = ln_params256(a.lnc_w, a.lnc_b);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int m = m0 + wave * 8 + rr, mc = m < a.M ? m : 0;
+            const int seq = mc / a.seq_rows;
+            const size_t prow = (size_t)seq * a.seq_stride + (mc % a.seq_rows);
+            xv[rr] = *reinterpret_cast<const float4*>(a.x + prow * 256 + lane * 4);
+            cv[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.cvec != nullptr) cv[rr] = *reinterpret_cast<const float4*>(a.cvec + (size_t)seq * a.cvec_ld + lane * 4);
         }
-        *reinterpret_cast<float4*>(Xs + row * ld + lane * 4) = v;
-        const unsigned lo = (unsigned)f2h(v.x) | ((unsigned)f2h(v.y) << 16), hi = (unsigned)f2h(v.z) | ((unsigned)f2h(v.w) << 16);
-        *reinterpret_cast<uint2*>(Xh + row * ldh + lane * 4) = make_uint2(lo, hi);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr, m = m0 + row;
+            float4 v = xv[rr];
+            if (a.cvec != nullptr) {
+                v = make_float4(v.x + cv[rr].x, v.y + cv[rr].y, v.z + cv[rr].z, v.w + cv[rr].w);
+                v = wave_layernorm256(v, lc, a.eps);
+            }
+            if (m >= a.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(Xs + row * ld + lane * 4) = v;
+            const unsigned lo = (unsigned)f2h(v.x) | ((unsigned)f2h(v.y) << 16), hi = (unsigned)f2h(v.z) | ((unsigned)f2h(v.w) << 16);
+            *reinterpret_cast<uint2*>(Xh + row * ldh + lane * 4) = make_uint2(lo, hi);
+        }
     }
     __syncthreads();
     const int ldhh = a.FF + HPAD;
@@ -473,14 +538,16 @@ __global__ __launch_bounds__(256) void k_ffn_block_h(const FfnHArgs a) {
         acc_store_lds<2, 4>(acc2, Cs, ld, wave * 64, a.b2, 0, 256, SEEME_ACT_NONE);
     }
     __syncthreads();
+    const LnParams lp = ln_params256(a.ln_w, a.ln_b), lf = ln_params256(a.fin_w, a.fin_b);
+#pragma unroll 2
     for (int rr = 0; rr < 8; ++rr) {
         const int row = wave * 8 + rr, m = m0 + row;
         if (m >= a.M) continue;
         float4 v = *reinterpret_cast<const float4*>(Cs + row * ld + lane * 4);
         const float4 x = *reinterpret_cast<const float4*>(Xs + row * ld + lane * 4);
         v = make_float4(v.x + x.x, v.y + x.y, v.z + x.z, v.w + x.w);
-        v = wave_layernorm256(v, a.ln_w, a.ln_b, a.eps);
-        if (a.fin_w != nullptr) v = wave_layernorm256(v, a.fin_w, a.fin_b, a.eps);
+        v = wave_layernorm256(v, lp, a.eps);
+        if (a.fin_w != nullptr) v = wave_layernorm256(v, lf, a.eps);
         const int seq = m / a.seq_rows, sr = m % a.seq_rows;
         size_t orow = (size_t)seq * a.seq_stride + sr;
         if (a.out_mode == 1) orow = (size_t)sr * (a.M / a.seq_rows) + seq;
