@@ -1,0 +1,22 @@
+"""Debug (build with -DH16_DBG_TIMES -DH16_DBG_KERNEL=k): cycle stamps of one workgroup of a fp16 VAE kernel at its phase
+boundaries during a default bench pass (the last launch of the kernel in the pass is reported)."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from seeme_amd import _lib as L
+import bench
+names = {1: ["Q tile -> LDS", "Q K^T + scores", "softmax", "P V", "out_proj", "residual + LN + store"],
+         2: ["stage A tile", "GEMM", "acc -> LDS + barrier", "epilogue"]}
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+sys.argv = [sys.argv[0], "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+bench.main()
+f = L.lib().seeme_debug_h16_times
+f.restype = C.c_int
+f.argtypes = [C.c_void_p, C.c_int]
+buf = (C.c_ulonglong * 32)()
+L.check(f(buf, 32))
+n = len(names[k]) + 1
+t = np.array(buf[:n], dtype=np.float64)
+print("kernel", k, "total", t[-1] - t[0])
+for nm, d in zip(names[k], np.diff(t)):
+    print(f"  {nm}: {d:.0f}")

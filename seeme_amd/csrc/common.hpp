@@ -88,11 +88,15 @@ __device__ __forceinline__ void tile_gemm_f32(const float* __restrict__ As, int 
                 float4 a[MTL], b[NTL];
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt) b[nt] = br[u][nt];
-                const int kn = (kb + PF < K16) ? kb + PF : K16 - 1;
-#pragma unroll
-                for (int nt = 0; nt < NTL; ++nt) br[u][nt] = *reinterpret_cast<const float4*>(wp[nt] + kn * 16);
 #pragma unroll
                 for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
+                // the slot is re-filled HERE, above this k-block's MFMAs, and the scheduler is fenced: left alone it
+                // sinks the loads to just before their use (vmcnt(0) per k-block: one L2 round trip per 16 k)
+                if (kb + PF < K16) {
+#pragma unroll
+                    for (int nt = 0; nt < NTL; ++nt) br[u][nt] = *reinterpret_cast<const float4*>(wp[nt] + (kb + PF) * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 // j outermost: MTL*NTL independent accumulators between two uses of the same one
                 // (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency)
 #pragma unroll
@@ -111,6 +115,7 @@ __device__ __forceinline__ void tile_gemm_f32(const float* __restrict__ As, int 
                 for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -151,9 +156,10 @@ __device__ __forceinline__ void tile_gemm_f32_kn(const float* __restrict__ As, i
                 for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) b[nt][j] = br[u][nt][j];
-                fetch((kb + PF < K16) ? kb + PF : K16 - 1, br[u]);
 #pragma unroll
                 for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
+                if (kb + PF < K16) fetch(kb + PF, br[u]);
+                __builtin_amdgcn_sched_barrier(0);            // (see tile_gemm_f32)
 #pragma unroll
                 for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
@@ -163,6 +169,7 @@ __device__ __forceinline__ void tile_gemm_f32_kn(const float* __restrict__ As, i
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt][2], acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt][3], acc[mt][nt], 0, 0, 0);
                     }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }

@@ -25,6 +25,21 @@ __device__ __forceinline__ float h_gelu(float x) {
 }
 __device__ __forceinline__ float h_act(float v, int act) { return act == SEEME_ACT_GELU ? h_gelu(v) : act_apply(v, act); }
 
+#ifdef H16_DBG_TIMES
+// debug build only: cycle stamps of one workgroup of one kernel (H16_DBG_KERNEL: 1 attention, 2 linear, 3 ffn, 4 qkv) at its
+// phase boundaries; the last launch of the pass wins (scripts/h16_times.py)
+__device__ unsigned long long h16_dbg_times[32];
+#ifndef H16_DBG_KERNEL
+#define H16_DBG_KERNEL 1
+#endif
+#define H16_DBG(k, i) do { if (H16_DBG_KERNEL == (k) && blockIdx.x == 3 && blockIdx.y == ((k) == 1 ? 5 : 0) && threadIdx.x == 0) h16_dbg_times[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int seeme_debug_h16_times(unsigned long long* host, int n) {
+    SEEME_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(h16_dbg_times), sizeof(unsigned long long) * (size_t)(n < 32 ? n : 32)));
+    return 0;
+}
+#else
+#define H16_DBG(k, i) do {} while (0)
+#endif
 #ifndef H16_PF
 #define H16_PF 2      // k-blocks of weight fragments in flight in the tile GEMMs (measured: 4 is no faster)
 #endif
@@ -125,14 +140,15 @@ __global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Kp = (a.K + 31) & ~31;
     const int lda_f = Kp + LDS_PAD, lda_h = Kp + HPAD;
-    const bool fast = ha.fast != 0;
+    const bool fast = ha.fast != 0;                                    // 1: plain float4 staging, 2: + LayerNorm over K = 256 in registers
     float* Af = smem;                                                  // [32][Kp+8] fp32 staging (pre-LN / act); absent in the fast path
     float* Cs = fast ? smem : Af + TILE_M * lda_f;                     // [32][264]
     unsigned short* Ah = reinterpret_cast<unsigned short*>(Cs + TILE_M * (CH_N + LDS_PAD));   // [32][Kp+16] fp16
     const int ldc = CH_N + LDS_PAD;
     const int m0 = blockIdx.x * TILE_M, cn0 = blockIdx.y * CH_N;
+    H16_DBG(2, 0);
 
-    if (fast) {   // float4 in, 4 halves out, no fp32 staging tile
+    if (ha.fast == 1) {   // float4 in, 4 halves out, no fp32 staging tile
         // Batches of 8 guarded loads per thread, ALL issued before the first is converted.  Written as
         // "if (valid) v = load" per element the compiler emitted branch + load + vmcnt(0) per iteration: 8-16
         // serialized memory round trips per tile, most of the time of these latency-bound kernels.  The guard is a
@@ -164,6 +180,28 @@ __global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
                     *reinterpret_cast<uint2*>(Ah + row * lda_h + 4 * c4) = make_uint2(lo, hi);
                 }
             }
+        }
+        __syncthreads();
+    } else if (ha.fast == 2) {   // pre-LayerNorm over K = 256: a wave normalises its 8 rows in registers (4 columns per lane)
+        const LnParams lp = ln_params256(a.pre_ln_w, a.pre_ln_b);
+        float4 xv[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int m = m0 + wave * 8 + rr;
+            int prow = m < a.M ? m : 0;
+            if (ka.seq_in > 0) prow = (prow / ka.seq_in) * ka.in_stride + (prow % ka.seq_in) + ka.in_off;
+            xv[rr] = *reinterpret_cast<const float4*>(a.A + (size_t)prow * a.lda + lane * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr;
+            float4 v = wave_layernorm256(xv[rr], lp, a.eps);
+            if (a.pre_act != SEEME_ACT_NONE)
+                v = make_float4(act_apply(v.x, a.pre_act), act_apply(v.y, a.pre_act), act_apply(v.z, a.pre_act), act_apply(v.w, a.pre_act));
+            if (m0 + row >= a.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned lo = (unsigned)f2h(v.x) | ((unsigned)f2h(v.y) << 16), hi = (unsigned)f2h(v.z) | ((unsigned)f2h(v.w) << 16);
+            *reinterpret_cast<uint2*>(Ah + row * lda_h + lane * 4) = make_uint2(lo, hi);
         }
         __syncthreads();
     } else {
@@ -198,12 +236,15 @@ __global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
         __syncthreads();
     }
 
+    H16_DBG(2, 1);
     f32x4 acc[2][4];
     acc_zero(acc);
     const int n0 = cn0 + wave * 64;
     if (n0 < a.N) gemm_packed<2, 4>(Ah, lda_h, ha.wp, ha.kstride, n0 >> 4, ha.ntiles, Kp >> 5, acc);
+    H16_DBG(2, 2);
     acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, a.bias, cn0, a.N, a.act);
     __syncthreads();
+    H16_DBG(2, 3);
 
     if (ha.qkv_mode) {
         if (blockIdx.y < 2) {          // q | k -> fp16 rows [M][512]
@@ -276,6 +317,7 @@ __global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
             if (g + 3 < a.N) yp[3] = v.w;
         }
     }
+    H16_DBG(2, 4);
 }
 
 static int launch_linear_h(const LinearHArgs& ha, hipStream_t st) {
@@ -284,7 +326,9 @@ static int launch_linear_h(const LinearHArgs& ha, hipStream_t st) {
     if (Kp > 512) return seeme_fail("linear_h: K > 512 not supported");
     if (a.ln_w && a.N != 256) return seeme_fail("linear_h: fused LayerNorm needs N == 256");
     LinearHArgs h2 = ha;
-    h2.fast = linear_h_fast(a) ? 1 : 0;
+    const bool ln_fast = a.pre_ln_w != nullptr && a.K == 256 && a.K1 == 256 && a.A2 == nullptr && ((a.lda & 3) == 0) &&
+                         ((reinterpret_cast<size_t>(a.A) & 15) == 0);
+    h2.fast = linear_h_fast(a) ? 1 : (ln_fast ? 2 : 0);
     // the fast path needs no fp32 staging tile: 51 KB (K = 256) instead of 85 KB, i.e. 3 workgroups per CU instead of 1
     const size_t lds = (size_t)((h2.fast ? 0 : TILE_M * (Kp + LDS_PAD)) + TILE_M * (CH_N + LDS_PAD)) * 4 + (size_t)TILE_M * (Kp + HPAD) * 2;
     dim3 grid((a.M + TILE_M - 1) / TILE_M, (a.N + CH_N - 1) / CH_N);
@@ -372,6 +416,38 @@ struct AttnHArgs {
 #ifndef ATT_PF
 #define ATT_PF 2    // k-blocks of B operands (K rows, V^T rows, W_o) in flight: the tile is latency-bound, not MFMA-bound
 #endif
+template <int NC>      // NC = Sp / 64 score columns per lane
+__device__ __forceinline__ void attn_softmax_rows(const float* __restrict__ Ps, int ldp, unsigned short* __restrict__ Ph, int ldph,
+                                                  int wave, int lane) {
+    float v[8][NC], mx[8], sum[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const float* prow = Ps + (wave * 8 + rr) * ldp + lane;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) v[rr][j] = prow[64 * j];
+        mx[rr] = v[rr][0];
+#pragma unroll
+        for (int j = 1; j < NC; ++j) mx[rr] = fmaxf(mx[rr], v[rr][j]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) mx[rr] = wave_max(mx[rr]);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        sum[rr] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { v[rr][j] = h_exp(v[rr][j] - mx[rr]); sum[rr] += v[rr][j]; }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) sum[rr] = wave_sum(sum[rr]);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const float inv = __builtin_amdgcn_rcpf(sum[rr]);
+        unsigned short* hrow = Ph + (wave * 8 + rr) * ldph + lane;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) hrow[64 * j] = f2h(v[rr][j] * inv);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
@@ -388,14 +464,24 @@ __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
     const int q0 = qt * TILE_M;
     const size_t base = (size_t)b * a.S;
     const int n_valid_keys = min(a.S, a.n_prefix + a.lengths[b]);
+    H16_DBG(1, 0);
 
-    for (int idx = tid; idx < TILE_M * 32; idx += 256) {       // Q tile, 8 halves per thread
-        const int row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (s < a.q_rows) v = *reinterpret_cast<const uint4*>(a.qk + (base + s) * 512 + c8);
-        *reinterpret_cast<uint4*>(Qh + row * ldq + c8) = v;
+    {   // Q tile, 8 halves per thread x 4, requested together (guard = select on address and value, no branch per load)
+        uint4 qv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + it * 256, row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
+            qv[it] = *reinterpret_cast<const uint4*>(a.qk + (base + (s < a.q_rows ? s : 0)) * 512 + c8);
+            if (s >= a.q_rows) qv[it] = make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + it * 256, row = idx >> 5, c8 = (idx & 31) * 8;
+            *reinterpret_cast<uint4*>(Qh + row * ldq + c8) = qv[it];
+        }
     }
     __syncthreads();
+    H16_DBG(1, 1);
     const unsigned short* Kmat = a.qk + base * 512 + 256;
     for (int c0 = 0; c0 < a.Sp; c0 += CH_N) {
         const int n0 = c0 + wave * 64;
@@ -413,18 +499,14 @@ __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
         }
     }
     __syncthreads();
-    for (int rr = 0; rr < 8; ++rr) {                           // softmax (fp32) -> fp16 probabilities; one exp per element
-        float* prow = Ps + (wave * 8 + rr) * ldp;
-        unsigned short* hrow = Ph + (wave * 8 + rr) * ldph;
-        float mx = -INFINITY;
-        for (int c = lane; c < a.Sp; c += 64) mx = fmaxf(mx, prow[c]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int c = lane; c < a.Sp; c += 64) { const float e = h_exp(prow[c] - mx); prow[c] = e; sum += e; }
-        const float inv = __builtin_amdgcn_rcpf(wave_sum(sum));
-        for (int c = lane; c < a.Sp; c += 64) hrow[c] = f2h(prow[c] * inv);
-    }
+    H16_DBG(1, 2);
+    // softmax (fp32) -> fp16 probabilities, one exp per element.  The wave's 8 rows are held in registers and reduced
+    // TOGETHER: row after row, every row paid two dependent wave reductions and three LDS passes in sequence
+    // (16.8 k of the tile's 47 k cycles); unrolled, the eight chains interleave.
+    if (a.Sp == 256) attn_softmax_rows<4>(Ps, ldp, Ph, ldph, wave, lane);
+    else attn_softmax_rows<8>(Ps, ldp, Ph, ldph, wave, lane);
     __syncthreads();
+    H16_DBG(1, 3);
     {   // O = P V : contraction over keys, V^T rows are the B operand
         f32x4 acc[2][4];
         acc_zero(acc);
@@ -433,6 +515,7 @@ __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
         acc_store_h16<2, 4>(acc, Qh, ldq, wave * 64, nullptr, SEEME_ACT_NONE);
     }
     __syncthreads();
+    H16_DBG(1, 4);
     float* Cs = Ps;
     const int ldc = 256 + LDS_PAD;
     {
@@ -442,6 +525,7 @@ __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
         acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, a.bo, 0, 256, SEEME_ACT_NONE);
     }
     __syncthreads();
+    H16_DBG(1, 5);
     {   // residual rows and LayerNorm parameters requested together, then one pass of LN + store per row
         const LnParams lp = ln_params256(a.ln_w, a.ln_b);
         float4 xr[8];
@@ -461,6 +545,7 @@ __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
             *reinterpret_cast<float4*>(a.out + (base + s) * 256 + lane * 4) = v;
         }
     }
+    H16_DBG(1, 6);
 }
 
 static int launch_attn_h(const AttnHArgs& a_in, int B, hipStream_t st) {
