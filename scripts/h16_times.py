@@ -6,7 +6,9 @@ import numpy as np
 from seeme_amd import _lib as L
 import bench
 names = {1: ["Q tile -> LDS", "Q K^T + scores", "softmax", "P V", "out_proj", "residual + LN + store"],
-         2: ["stage A tile", "GEMM", "acc -> LDS + barrier", "epilogue"]}
+         2: ["stage A tile", "GEMM", "acc -> LDS + barrier", "epilogue"],
+         3: ["stage rows (+ cross-attention vector, LN)", "GEMM1 + hidden -> LDS", "GEMM2 + tile -> LDS", "residual + LN + store"],
+         4: ["stage 128 rows", "GEMM", "barrier + acc -> LDS", "stores (q|k rows / V transposed)"]}
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 sys.argv = [sys.argv[0], "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
 bench.main()

@@ -205,6 +205,35 @@ __device__ __forceinline__ void acc_store_lds(const f32x4 (&acc)[MTL][NTL], floa
     }
 }
 
+// Bias values of a wave's NTL output column tiles, requested BEFORE the GEMM whose epilogue adds them (read inside the
+// epilogue they are one more dependent L2 round trip per phase of these latency-bound tiles).
+template <int NTL>
+struct BiasRegs { float v[NTL]; };
+template <int NTL>
+__device__ __forceinline__ BiasRegs<NTL> bias_load(const float* __restrict__ bias, int gcol, int n_valid) {
+    const int r = threadIdx.x & 15;
+    BiasRegs<NTL> b;
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int g = gcol + nt * 16 + r;
+        b.v[nt] = (bias != nullptr && g < n_valid) ? bias[g] : 0.f;
+    }
+    return b;
+}
+template <int MTL, int NTL>
+__device__ __forceinline__ void acc_store_lds(const f32x4 (&acc)[MTL][NTL], float* __restrict__ Cs, int ldc,
+                                              int c0, const BiasRegs<NTL>& bias, int act) {
+    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int c = c0 + nt * 16 + r;
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Cs[(mt * 16 + 4 * kq + i) * ldc + c] = act_apply(acc[mt][nt][i] + bias.v[nt], act);
+    }
+}
+
 // LayerNorm of one 256-wide row held 4 floats per lane by a full wave (two-pass, torch semantics).
 // LayerNorm parameters of this lane's 4 columns, loaded once per kernel phase: inside a row loop that also stores
 // to global memory the compiler re-reads them per row, and every row then waits on an L2 round trip.

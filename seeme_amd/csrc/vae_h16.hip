@@ -43,6 +43,9 @@ extern "C" int seeme_debug_h16_times(unsigned long long* host, int n) {
 #ifndef H16_PF
 #define H16_PF 2      // k-blocks of weight fragments in flight in the tile GEMMs (measured: 4 is no faster)
 #endif
+#ifndef FFN_PF
+#define FFN_PF H16_PF  // the FFN's first GEMM (2 n-tiles per wave)
+#endif
 template <int MTL, int NTL, int PF, typename LoadB>
 __device__ __forceinline__ void tile_gemm_h16(const unsigned short* __restrict__ As, int lda, int K32, LoadB loadb,
                                               f32x4 (&acc)[MTL][NTL]) {
@@ -116,6 +119,20 @@ __device__ __forceinline__ void acc_store_h16(const f32x4 (&acc)[MTL][NTL], unsi
         for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) Hs[(mt * 16 + 4 * kq + i) * ldh + c] = f2h(h_act(acc[mt][nt][i] + bv, act));
+    }
+}
+
+template <int MTL, int NTL>
+__device__ __forceinline__ void acc_store_h16(const f32x4 (&acc)[MTL][NTL], unsigned short* __restrict__ Hs, int ldh, int c0,
+                                              const BiasRegs<NTL>& bias, int act) {
+    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int c = c0 + nt * 16 + r;
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Hs[(mt * 16 + 4 * kq + i) * ldh + c] = f2h(h_act(acc[mt][nt][i] + bias.v[nt], act));
     }
 }
 
@@ -240,9 +257,10 @@ __global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
     f32x4 acc[2][4];
     acc_zero(acc);
     const int n0 = cn0 + wave * 64;
+    const BiasRegs<4> bias = bias_load<4>(a.bias, n0, a.N);
     if (n0 < a.N) gemm_packed<2, 4>(Ah, lda_h, ha.wp, ha.kstride, n0 >> 4, ha.ntiles, Kp >> 5, acc);
     H16_DBG(2, 2);
-    acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, a.bias, cn0, a.N, a.act);
+    acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, bias, a.act);
     __syncthreads();
     H16_DBG(2, 3);
 
@@ -351,6 +369,7 @@ __global__ __launch_bounds__(512) void k_qkv_h(const LinearHArgs ha) {
     constexpr int LDH = 256 + HPAD;
     unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);            // [128][272] fp16 operand tile, later the output tile
     const int m0 = blockIdx.x * QKV_MT, y = blockIdx.y;
+    H16_DBG(4, 0);
     {   // stage: 128 rows x 64 float4, all of a thread's loads in flight together
         constexpr int NIT = QKV_MT * 64 / 512;
         float4 v[NIT];
@@ -370,12 +389,16 @@ __global__ __launch_bounds__(512) void k_qkv_h(const LinearHArgs ha) {
         }
     }
     __syncthreads();
+    H16_DBG(4, 1);
     f32x4 acc[4][4];
     acc_zero(acc);
+    const BiasRegs<4> bias = bias_load<4>(a.bias, y * 256 + nq * 64, 768);
     gemm_packed<4, 4>(Ah + mh * 64 * LDH, LDH, ha.wp, ha.kstride, y * 16 + nq * 4, ha.ntiles, 8, acc);
+    H16_DBG(4, 2);
     __syncthreads();                                                          // operand tile consumed: it becomes the output tile
-    acc_store_h16<4, 4>(acc, Ah + mh * 64 * LDH, LDH, nq * 64, a.bias + y * 256, SEEME_ACT_NONE);
+    acc_store_h16<4, 4>(acc, Ah + mh * 64 * LDH, LDH, nq * 64, bias, SEEME_ACT_NONE);
     __syncthreads();
+    H16_DBG(4, 3);
     if (y < 2) {            // q | k: fp16 rows, 16-byte coalesced stores
         for (int idx = tid; idx < QKV_MT * 32; idx += 512) {
             const int row = idx >> 5, c8 = (idx & 31) * 8, m = m0 + row;
@@ -393,6 +416,7 @@ __global__ __launch_bounds__(512) void k_qkv_h(const LinearHArgs ha) {
             }
         }
     }
+    H16_DBG(4, 4);
 }
 static int launch_qkv_h(const LinearHArgs& ha, hipStream_t st) {
     const SeemeLinearArgs& a = ha.k.a;
@@ -521,8 +545,9 @@ __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
     {
         f32x4 acc[2][4];
         acc_zero(acc);
+        const BiasRegs<4> bias = bias_load<4>(a.bo, wave * 64, 256);
         gemm_packed<2, 4, ATT_PF>(Qh, ldq, a.wo, 8, wave * 4, 16, 8, acc);
-        acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, a.bo, 0, 256, SEEME_ACT_NONE);
+        acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, bias, SEEME_ACT_NONE);
     }
     __syncthreads();
     H16_DBG(1, 5);
@@ -580,6 +605,9 @@ __global__ __launch_bounds__(256) void k_ffn_block_h(const FfnHArgs a) {
     unsigned short* Xh = reinterpret_cast<unsigned short*>(Cs);            // ... whose head first holds the [32][272] fp16 A operand
                                                                            // (dead once the hidden layer is formed: 77 KB, 2 workgroups/CU)
     const int m0 = blockIdx.x * TILE_M;
+    const BiasRegs<2> bias1 = bias_load<2>(a.b1, wave * 32, a.FF);
+    const BiasRegs<4> bias2 = bias_load<4>(a.b2, wave * 64, 256);
+    H16_DBG(3, 0);
     {   // the wave's 8 rows (and their cross-attention vectors) are requested together, then normalised / converted
         float4 xv[8], cv[8];
         const LnParams lc = ln_params256(a.lnc_w, a.lnc_b);
@@ -608,21 +636,24 @@ __global__ __launch_bounds__(256) void k_ffn_block_h(const FfnHArgs a) {
         }
     }
     __syncthreads();
+    H16_DBG(3, 1);
     const int ldhh = a.FF + HPAD;
     {   // hidden = act(W1 x + b1): FF = 128 -> 32 columns per wave
         f32x4 acc1[2][2];
         acc_zero(acc1);
-        gemm_packed<2, 2>(Xh, ldh, a.w1, 8, wave * 2, a.FF >> 4, 8, acc1);
-        acc_store_h16<2, 2>(acc1, Hh, ldhh, wave * 32, a.b1, a.act);
+        gemm_packed<2, 2, FFN_PF>(Xh, ldh, a.w1, 8, wave * 2, a.FF >> 4, 8, acc1);
+        acc_store_h16<2, 2>(acc1, Hh, ldhh, wave * 32, bias1, a.act);
     }
     __syncthreads();
+    H16_DBG(3, 2);
     {
         f32x4 acc2[2][4];
         acc_zero(acc2);
         gemm_packed<2, 4>(Hh, ldhh, a.w2, a.FF >> 5, wave * 4, 16, a.FF >> 5, acc2);
-        acc_store_lds<2, 4>(acc2, Cs, ld, wave * 64, a.b2, 0, 256, SEEME_ACT_NONE);
+        acc_store_lds<2, 4>(acc2, Cs, ld, wave * 64, bias2, SEEME_ACT_NONE);
     }
     __syncthreads();
+    H16_DBG(3, 3);
     const LnParams lp = ln_params256(a.ln_w, a.ln_b), lf = ln_params256(a.fin_w, a.fin_b);
 #pragma unroll 2
     for (int rr = 0; rr < 8; ++rr) {
@@ -638,6 +669,7 @@ __global__ __launch_bounds__(256) void k_ffn_block_h(const FfnHArgs a) {
         if (a.out_mode == 1) orow = (size_t)sr * (a.M / a.seq_rows) + seq;
         *reinterpret_cast<float4*>(a.out + orow * 256 + lane * 4) = v;
     }
+    H16_DBG(3, 4);
 }
 
 static int launch_ffn_h(const FfnHArgs& a, hipStream_t st) {
