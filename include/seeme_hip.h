@@ -295,6 +295,15 @@ size_t seeme_pointnet_bf16_workspace_bytes(int B, int P);
 int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const SeemePointnetBf16* wb, const float* points,
                                int B, int P, float* out, void* workspace, size_t ws_bytes, void* stream);
 
+/* AdamW step of a list of fp32 tensors in one launch, torch.optim.AdamW arithmetic (amsgrad off): replaces the
+ * optimiser step Lightning runs after training_step (reference: mld/models/modeltype/base.py configure_optimizers,
+ * train.py:127-149).  chunks: device array of {int tensor, int count, int64 offset}; params / grads / exp_avg /
+ * exp_avg_sq: device arrays of per-tensor base pointers; step = the 1-based step count (bias corrections and the
+ * other scalar factors are formed in double, as PyTorch forms them). */
+int seeme_adamw_step(const void* chunks, int n_chunks, void* const* params, const void* const* grads, void* const* exp_avg,
+                     void* const* exp_avg_sq, double lr, double beta1, double beta2, double eps, double weight_decay,
+                     double step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,9 +32,29 @@ for it in range(6):
     model.optimizer.zero_grad(set_to_none=True)
     loss.backward()
     e[2].record()
-    model.optimizer.step()
+    model.optimizer_update()
     e[3].record()
     torch.cuda.synchronize(); t1 = time.perf_counter()
     if it >= 3:
         print(json.dumps({"fwd_ms": round(e[0].elapsed_time(e[1]), 2), "backward_ms": round(e[1].elapsed_time(e[2]), 2),
                           "adamw_ms": round(e[2].elapsed_time(e[3]), 2), "wall_ms": round((t1 - t0) * 1e3, 2)}))
+
+if "prof" in sys.argv[1:]:
+    import collections
+    from torch.profiler import profile, ProfilerActivity
+    rs = model.train_diffusion_forward(batch)
+    loss = model.losses["train"].update(rs)
+    model.optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        model.optimizer_update()
+        torch.cuda.synchronize()
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for e in prof.events():
+        if e.device_type.name != "CPU":
+            agg[e.name[:80]][0] += 1; agg[e.name[:80]][1] += e.device_time
+    print("optimizer.step device kernels:", sum(v[0] for v in agg.values()), "total us", round(sum(v[1] for v in agg.values()), 1))
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]:
+        print(f"  {v[1]:8.1f} us {v[0]:4d}x {k}")
+    print("trainable tensors", len(model.trainable_parameters()), "elements", sum(p.numel() for p in model.trainable_parameters()))

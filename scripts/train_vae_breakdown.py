@@ -26,7 +26,7 @@ def step(rec=None):
     model.optimizer.zero_grad(set_to_none=True)
     loss.backward()
     e[2].record()
-    model.optimizer.step()
+    model.optimizer_update()
     e[3].record()
     torch.cuda.synchronize()
     return {"fwd_ms": round(e[0].elapsed_time(e[1]), 2), "backward_ms": round(e[1].elapsed_time(e[2]), 2), "adamw_ms": round(e[2].elapsed_time(e[3]), 2)}

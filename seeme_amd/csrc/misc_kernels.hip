@@ -152,3 +152,54 @@ extern "C" int seeme_pointnet_encode(const SeemePointnetWeights* w, const float*
     // fc_c(relu(pooled))  -> [B, out_dim]
     return lin(st, pool2, H, w->fcc_w, H, w->fcc_b, nullptr, 0, 0, out, B, w->out_dim, H, SEEME_ACT_RELU);
 }
+
+// ---------------------------------------------------------------------------------------------
+// AdamW over a list of tensors in ONE launch (torch.optim.AdamW arithmetic, amsgrad off).  The reference trains with
+// Lightning's default AdamW (mld/models/modeltype/base.py: configure_optimizers); PyTorch's multi-tensor path spends
+// 27 launches and ~0.5 ms on the 204 trainable tensors (8.0 M elements) of stage 2, a pure HBM stream of 224 MB.
+// chunks[c] = {tensor id, element offset, element count}; p / m / v / g = per-tensor base pointers.
+struct AdamWChunk { int tensor, count; long long offset; };
+__global__ __launch_bounds__(256) void k_adamw(const AdamWChunk* __restrict__ chunks, float* const* __restrict__ ps,
+                                               const float* const* __restrict__ gs, float* const* __restrict__ ms,
+                                               float* const* __restrict__ vs, float decay, float one_minus_beta1, float beta2,
+                                               float one_minus_beta2, float step_size, float sqrt_bias_c2, float eps) {
+    const AdamWChunk ch = chunks[blockIdx.x];
+    float* __restrict__ p = ps[ch.tensor] + ch.offset;
+    const float* __restrict__ g = gs[ch.tensor] + ch.offset;
+    float* __restrict__ m = ms[ch.tensor] + ch.offset;
+    float* __restrict__ v = vs[ch.tensor] + ch.offset;
+    // the scalar factors (1 - lr wd, 1 - beta, lr / bias_correction1) are formed in double on the host, as PyTorch does
+    auto upd = [&](float& pw, float gw, float& mw, float& vw) {
+        pw *= decay;                                               // p.mul_(1 - lr * wd)
+        mw = mw + (gw - mw) * one_minus_beta1;                     // exp_avg.lerp_(grad, 1 - beta1)
+        vw = vw * beta2 + gw * gw * one_minus_beta2;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        pw -= step_size * (mw / (sqrtf(vw) / sqrt_bias_c2 + eps)); // p.addcdiv_(exp_avg, denom, -step_size)
+    };
+    const bool vec = ((reinterpret_cast<size_t>(p) | reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(m) | reinterpret_cast<size_t>(v)) & 15) == 0;
+    if (vec) {
+        const int n4 = ch.count >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            float4 pw = reinterpret_cast<float4*>(p)[i], mw = reinterpret_cast<float4*>(m)[i], vw = reinterpret_cast<float4*>(v)[i];
+            const float4 gw = reinterpret_cast<const float4*>(g)[i];
+            upd(pw.x, gw.x, mw.x, vw.x); upd(pw.y, gw.y, mw.y, vw.y); upd(pw.z, gw.z, mw.z, vw.z); upd(pw.w, gw.w, mw.w, vw.w);
+            reinterpret_cast<float4*>(p)[i] = pw; reinterpret_cast<float4*>(m)[i] = mw; reinterpret_cast<float4*>(v)[i] = vw;
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < ch.count; i += 256) upd(p[i], g[i], m[i], v[i]);
+    } else {
+        for (int i = threadIdx.x; i < ch.count; i += 256) upd(p[i], g[i], m[i], v[i]);
+    }
+}
+
+extern "C" int seeme_adamw_step(const void* chunks, int n_chunks, void* const* params, const void* const* grads, void* const* exp_avg,
+                                void* const* exp_avg_sq, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                double step, void* stream) {
+    if (n_chunks <= 0) return 0;
+    if (!(step >= 1.0)) return seeme_fail("adamw: step must be >= 1");
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    hipLaunchKernelGGL(k_adamw, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamWChunk*)chunks,
+                       (float* const*)params, (const float* const*)grads, (float* const*)exp_avg, (float* const*)exp_avg_sq,
+                       (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                       (float)(lr / bc1), (float)sqrt(bc2), (float)eps);
+    return seeme_check_launch("k_adamw");
+}
+

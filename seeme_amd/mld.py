@@ -305,7 +305,20 @@ class MLD(nn.Module):
             self.optimizer = torch.optim.AdamW(params, lr=self.cfg.TRAIN.OPTIM.LR, capturable=capturable)
             self.sch = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=self.cfg.TRAIN.OPTIM.STEP_SIZE,
                                                        gamma=self.cfg.TRAIN.OPTIM.GAMMA)
+            # eager steps update all tensors in one launch (seeme_adamw_step) on this optimiser's own state; the
+            # hipGraph-captured step (capturable=True) stays on PyTorch's AdamW
+            self._fused_adamw = None
+            if not capturable and bool(self.cfg.TRAIN.get("FUSED_ADAMW", True)) and params and all(p.is_cuda for p in params):
+                from .optim import FusedAdamWStep
+                self._fused_adamw = FusedAdamWStep(self.optimizer)
         return {"optimizer": self.optimizer}
+
+    def optimizer_update(self):
+        """The AdamW update of the trainable tensors (after backward and the gradient all-reduce)."""
+        if getattr(self, "_fused_adamw", None) is not None:
+            self._fused_adamw.step()
+        else:
+            self.optimizer.step()
 
     def trainable_parameters(self):
         return [p for p in self.parameters() if p.requires_grad]
@@ -612,4 +625,4 @@ class MLD(nn.Module):
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         D.allreduce_gradients(self.trainable_parameters())
-        self.optimizer.step()
+        self.optimizer_update()
