@@ -394,14 +394,26 @@ class MLD(nn.Module):
         lengths = [feats_ref.shape[1]] * feats_ref.shape[0]
         with torch.no_grad():
             idx = 0 if self.estimate == "wearer" else 1
-            z, _ = self.vae.encode(self._wearer_features(feats_ref, transl, idx), None, lengths)
+            f_tgt = self._wearer_features(feats_ref, transl, idx)
             z_cond = None
             if "interactee" in self.condition:
+                # target and interactee go through the frozen VAE as ONE batch of 2B sequences (the encode is a chain of
+                # ~20 latency-bound launches); the three random draws keep the order of the two separate encodes:
+                # rsample noise of the target, the CFG input mask, rsample noise of the condition (mld.py:944-984)
+                B = f_tgt.shape[0]
+                shape = (1, B, self.vae.latent_dim)
+                eps_z = torch.empty(shape, device=f_tgt.device, dtype=torch.float32).normal_()
                 f_int = self._wearer_features(feats_ref, transl, 1)
                 if self.do_classifier_free_guidance:                       # mld.py:966-981
                     mask = torch.rand_like(f_int) < self.guidance_uncodp
                     f_int = torch.where(mask, torch.zeros_like(f_int), f_int)
-                z_cond, _ = self.vae.encode(f_int, None, lengths)
+                eps_c = torch.empty(shape, device=f_tgt.device, dtype=torch.float32).normal_()
+                dist = self.vae.encode_dist(torch.cat([f_tgt, f_int], dim=0), lengths + lengths)      # [2, 2B, 256]
+                mu, std = dist[0:1], dist[1:2].exp().pow(0.5)              # mld_vae.py:186-190
+                z = mu[:, :B] + eps_z * std[:, :B]                         # Normal(mu, std).rsample(), :192
+                z_cond = mu[:, B:] + eps_c * std[:, B:]
+            else:
+                z, _ = self.vae.encode(f_tgt, None, lengths)
         if scene is not None and z_cond is not None:
             cond_emb = torch.cat([z_cond, scene], dim=0)                    # :991-993
         elif scene is not None:
