@@ -295,6 +295,12 @@ size_t seeme_pointnet_bf16_workspace_bytes(int B, int P);
 int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const SeemePointnetBf16* wb, const float* points,
                                int B, int P, float* out, void* workspace, size_t ws_bytes, void* stream);
 
+/* Weight gradients of the denoiser chain in one launch: for every tile {int x_col, y_col, ldo, nn, kk, pad; int64 out_off}
+ * out[out_off + n*ldo + k] = sum_b gout[b*ldg + y_col + n] * gout[b*ldg + x_col + k], n < nn <= 32, k < kk <= 256, where
+ * gout is the per-sample buffer of seeme_denoiser_backward (x and dy of every linear, csrc/den_train.h).  Replaces the
+ * autograd weight-gradient accumulation of loss.backward() through MldDenoiser.forward (mld.py:582-631). */
+int seeme_den_wgrad(const float* gout, int ldg, int B, const void* tiles, int n_tiles, float* out, void* stream);
+
 /* AdamW step of a list of fp32 tensors in one launch, torch.optim.AdamW arithmetic (amsgrad off): replaces the
  * optimiser step Lightning runs after training_step (reference: mld/models/modeltype/base.py configure_optimizers,
  * train.py:127-149).  chunks: device array of {int tensor, int count, int64 offset}; params / grads / exp_avg /

@@ -67,13 +67,22 @@ if "proffwd" in sys.argv[1:]:
         rs = model.train_diffusion_forward(batch)
         loss = model.losses["train"].update(rs)
         torch.cuda.synchronize()
+    fw = collections.defaultdict(lambda: [0, 0.0])
+    for e in prof.events():
+        if e.device_type.name != "CPU":
+            fw[e.name[:70]][0] += 1; fw[e.name[:70]][1] += e.device_time
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
         model.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         torch.cuda.synchronize()
+    print("forward device kernels:", sum(v[0] for v in fw.values()), "total us", round(sum(v[1] for v in fw.values()), 1))
+    for k, v in sorted(fw.items(), key=lambda kv: -kv[1][1])[:12]:
+        print(f"  {v[1]:8.1f} us {v[0]:4d}x {k}")
+    print("backward:")
     agg = collections.defaultdict(lambda: [0, 0.0])
     for e in prof.events():
         if e.device_type.name != "CPU":
             agg[e.name[:70]][0] += 1; agg[e.name[:70]][1] += e.device_time
-    print("fwd+bwd device kernels:", sum(v[0] for v in agg.values()), "total us", round(sum(v[1] for v in agg.values()), 1))
+    print("backward device kernels:", sum(v[0] for v in agg.values()), "total us", round(sum(v[1] for v in agg.values()), 1))
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
         print(f"  {v[1]:8.1f} us {v[0]:4d}x {k}")

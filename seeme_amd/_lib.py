@@ -120,6 +120,7 @@ _SIGNATURES = {
     "seeme_den_train_pack": (C.c_int, [fp, fp, fp, fp, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.c_int, fp, fp]),
     "seeme_denoiser_backward": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp]),
     "seeme_den_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "seeme_den_wgrad": (C.c_int, [fp, C.c_int, C.c_int, fp, C.c_int, fp, fp]),
     "seeme_adamw_step": (C.c_int, [fp, C.c_int, fp, fp, fp, fp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_double, fp]),
     "seeme_geometry": (C.c_int, [C.c_int, fp, fp, C.c_int, fp]),

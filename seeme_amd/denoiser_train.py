@@ -163,6 +163,18 @@ class TrainPack:
             for d in shape:
                 n *= d
             self.grad_views[pos] = self.gflat[o:o + n].view(*shape)
+        # tiles of seeme_den_wgrad: {int x_col, y_col, ldo, nn, kk, pad; int64 out_off} per 32 x 256 block of every matrix
+        tiles = []
+        for name, ls, moff, Nn, K in self.mat_blocks:
+            xo, _, yo, _ = _LIN[name]
+            for i, l in enumerate(ls):
+                for n0 in range(0, Nn, 32):
+                    for k0 in range(0, K, 256):
+                        o = moff + (i * Nn + n0) * K + k0
+                        tiles.append([l * DBL + _DB[xo] + k0, l * DBL + _DB[yo] + n0, K, min(32, Nn - n0), min(256, K - k0), 0,
+                                      o & 0xFFFFFFFF if o < 2 ** 31 else o - 2 ** 32, o >> 32])
+        self._wgrad_tiles = torch.tensor(tiles, dtype=torch.int32).to(dev)
+        self._n_wgrad_tiles = len(tiles)
         self.dpe = torch.zeros_like(self.params[0])                     # query_pos.pe: only row 0 is on the path
         self.grad_views[0] = self.dpe
         self.dx0_span = (fin + 512, fin + 768)
@@ -176,11 +188,15 @@ class TrainPack:
         flat = torch.empty_like(self.gflat) if live else self.gflat   # a previous backward's gradients are still in use
         colsum = gout.sum(0)
         G = gout[:, : 5 * DBL].view(B, 5, DBL)
-        for name, ls, off, Nn, K in self.mat_blocks:
-            xo, _, yo, _ = _LIN[name]
-            Y = G[:, ls[0]:ls[-1] + 1, _DB[yo]:_DB[yo] + Nn].permute(1, 2, 0)        # [L,N,B]
-            X = G[:, ls[0]:ls[-1] + 1, _DB[xo]:_DB[xo] + K].permute(1, 0, 2)         # [L,B,K]
-            torch.bmm(Y, X, out=flat[off:off + len(ls) * Nn * K].view(len(ls), Nn, K))
+        if gout.is_cuda:
+            L.check(L.lib().seeme_den_wgrad(gout.data_ptr(), gout.shape[1], B, self._wgrad_tiles.data_ptr(), self._n_wgrad_tiles,
+                                            flat.data_ptr(), L.current_stream()), "seeme_den_wgrad")
+        else:                                                                         # (CPU: shape tests of the host logic)
+            for name, ls, off, Nn, K in self.mat_blocks:
+                xo, _, yo, _ = _LIN[name]
+                Y = G[:, ls[0]:ls[-1] + 1, _DB[yo]:_DB[yo] + Nn].permute(1, 2, 0)    # [L,N,B]
+                X = G[:, ls[0]:ls[-1] + 1, _DB[xo]:_DB[xo] + K].permute(1, 0, 2)     # [L,B,K]
+                torch.bmm(Y, X, out=flat[off:off + len(ls) * Nn * K].view(len(ls), Nn, K))
         v0 = self.vec_region.data_ptr() - self.gflat.data_ptr()
         flat[v0 // 4:].copy_(colsum.index_select(0, self.gather_idx))
         dpe = self.dpe if not live else torch.zeros_like(self.dpe)
@@ -210,9 +226,17 @@ def _tables(den, cond_sf: torch.Tensor, emb: torch.Tensor):
     kv_w = torch.cat([b.sa_block.self_attn.in_proj_weight[256:] for b in blocks])    # [2560,256]: K|V per layer
     kv_b = torch.cat([b.sa_block.self_attn.in_proj_bias[256:] for b in blocks])
     sa_c = F.linear(cond, kv_w, kv_b)                                                # [B,N,2560]
-    ca_c = torch.cat([F.linear(F.layer_norm(cond, (256,), b.ca_block.text_norm.weight, b.ca_block.text_norm.bias),
-                               torch.cat([b.ca_block.key.weight, b.ca_block.value.weight]),
-                               torch.cat([b.ca_block.key.bias, b.ca_block.value.bias])) for b in blocks], dim=-1)
+    # text_norm of the five layers shares its statistics (only the affine part is per layer), and the five key|value
+    # projections are one batched GEMM: per layer they were 5 + 10 small GEMM launches of ~60 us each in forward + backward
+    Bc, Nc = cond.shape[0], cond.shape[1]
+    xhat = F.layer_norm(cond, (256,))                                                # [B,N,256]
+    tn_w = torch.stack([b.ca_block.text_norm.weight for b in blocks])                # [5,256]
+    tn_b = torch.stack([b.ca_block.text_norm.bias for b in blocks])
+    xl = (xhat.reshape(1, Bc * Nc, 256) * tn_w[:, None, :] + tn_b[:, None, :])       # [5,B*N,256]
+    ca_w = torch.stack([torch.cat([b.ca_block.key.weight, b.ca_block.value.weight]) for b in blocks])   # [5,512,256]
+    ca_b = torch.stack([torch.cat([b.ca_block.key.bias, b.ca_block.value.bias]) for b in blocks])       # [5,512]
+    ca_c = torch.baddbmm(ca_b[:, None, :], xl, ca_w.transpose(1, 2))                 # [5,B*N,512]
+    ca_c = ca_c.permute(1, 0, 2).reshape(Bc, Nc, 5 * 512)
     ctab = torch.cat([sa_c, ca_c], dim=-1).contiguous()
     st_w = torch.cat([torch.cat([b.ca_block.proj_out.emb_layers[1].weight, b.ffn.proj_out.emb_layers[1].weight]) for b in blocks])
     st_b = torch.cat([torch.cat([b.ca_block.proj_out.emb_layers[1].bias, b.ffn.proj_out.emb_layers[1].bias]) for b in blocks])
