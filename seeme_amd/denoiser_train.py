@@ -233,13 +233,14 @@ def _tables(den, cond_sf: torch.Tensor, emb: torch.Tensor):
     tn_w = torch.stack([b.ca_block.text_norm.weight for b in blocks])                # [5,256]
     tn_b = torch.stack([b.ca_block.text_norm.bias for b in blocks])
     xl = (xhat.reshape(1, Bc * Nc, 256) * tn_w[:, None, :] + tn_b[:, None, :])       # [5,B*N,256]
-    ca_w = torch.stack([torch.cat([b.ca_block.key.weight, b.ca_block.value.weight]) for b in blocks])   # [5,512,256]
-    ca_b = torch.stack([torch.cat([b.ca_block.key.bias, b.ca_block.value.bias]) for b in blocks])       # [5,512]
+    # (flat concatenations: one copy kernel per torch.cat call, nested cats were 33 launches per step)
+    ca_w = torch.cat([w for b in blocks for w in (b.ca_block.key.weight, b.ca_block.value.weight)]).view(5, 512, 256)
+    ca_b = torch.cat([w for b in blocks for w in (b.ca_block.key.bias, b.ca_block.value.bias)]).view(5, 512)
     ca_c = torch.baddbmm(ca_b[:, None, :], xl, ca_w.transpose(1, 2))                 # [5,B*N,512]
     ca_c = ca_c.permute(1, 0, 2).reshape(Bc, Nc, 5 * 512)
     ctab = torch.cat([sa_c, ca_c], dim=-1).contiguous()
-    st_w = torch.cat([torch.cat([b.ca_block.proj_out.emb_layers[1].weight, b.ffn.proj_out.emb_layers[1].weight]) for b in blocks])
-    st_b = torch.cat([torch.cat([b.ca_block.proj_out.emb_layers[1].bias, b.ffn.proj_out.emb_layers[1].bias]) for b in blocks])
+    st_w = torch.cat([w for b in blocks for w in (b.ca_block.proj_out.emb_layers[1].weight, b.ffn.proj_out.emb_layers[1].weight)])
+    st_b = torch.cat([w for b in blocks for w in (b.ca_block.proj_out.emb_layers[1].bias, b.ffn.proj_out.emb_layers[1].bias)])
     ttab = torch.cat([F.linear(emb, kv_w, kv_b), F.linear(F.silu(emb), st_w, st_b)], dim=-1).contiguous()
     return ctab, ttab
 
