@@ -441,8 +441,9 @@ struct AttnHArgs {
 #define ATT_PF 2    // k-blocks of B operands (K rows, V^T rows, W_o) in flight: the tile is latency-bound, not MFMA-bound
 #endif
 template <int NC>      // NC = Sp / 64 score columns per lane
-__device__ __forceinline__ void attn_softmax_rows(const float* __restrict__ Ps, int ldp, unsigned short* __restrict__ Ph, int ldph,
-                                                  int wave, int lane) {
+__device__ __forceinline__ void attn_softmax_rows(const float* Ps, int ldp, unsigned short* Ph, int ldph, int wave, int lane) {
+    // Ph MAY ALIAS Ps (no __restrict__): the fp16 probabilities of a row overwrite the head of its own fp32 score row, which
+    // is legal because a wave reads all of its 8 rows into registers before it writes any, and no other wave touches them
     float v[8][NC], mx[8], sum[8];
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
@@ -475,10 +476,11 @@ __device__ __forceinline__ void attn_softmax_rows(const float* __restrict__ Ps, 
 __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
-    const int ldp = a.Sp + LDS_PAD, ldq = 256 + HPAD, ldph = a.Sp + HPAD;
+    const int ldp = a.Sp + LDS_PAD, ldq = 256 + HPAD, ldph = 2 * ldp;
     float* Ps = smem;                                                       // [32][Sp+8] fp32 scores, later the out_proj tile
     unsigned short* Qh = reinterpret_cast<unsigned short*>(Ps + TILE_M * ldp);   // [32][272] Q, later O
-    unsigned short* Ph = Qh + TILE_M * ldq;                                 // [32][Sp+16] probabilities
+    unsigned short* Ph = reinterpret_cast<unsigned short*>(Ps);             // probabilities: fp16 rows in place of the score rows
+                                                                            // (50 KB instead of 68 KB per workgroup: 3 per CU)
     int b = blockIdx.y, qt = blockIdx.x;
     if ((gridDim.y & 7) == 0) {    // all query tiles of one sequence on one XCD (speed only)
         const int L = blockIdx.x + gridDim.x * blockIdx.y, rr = L & 7, q = L >> 3;
@@ -577,7 +579,7 @@ static int launch_attn_h(const AttnHArgs& a_in, int B, hipStream_t st) {
     AttnHArgs a = a_in;
     if (a.S <= 0 || a.S > 512) return seeme_fail("attention_h: S must be in 1..512");
     a.Sp = (a.S + CH_N - 1) / CH_N * CH_N;
-    const size_t lds = (size_t)TILE_M * (a.Sp + LDS_PAD) * 4 + (size_t)TILE_M * (256 + HPAD) * 2 + (size_t)TILE_M * (a.Sp + HPAD) * 2;
+    const size_t lds = (size_t)TILE_M * (a.Sp + LDS_PAD) * 4 + (size_t)TILE_M * (256 + HPAD) * 2;
     dim3 grid((a.q_rows + TILE_M - 1) / TILE_M, B);
     SEEME_HIP(hipFuncSetAttribute((const void*)k_attn_block_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_attn_block_h, grid, dim3(256), lds, st, a);
