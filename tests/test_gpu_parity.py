@@ -368,6 +368,18 @@ def test_mld_sample_vs_oracle_mpjpe(dev):
     print("MPJPE vs ground truth: HIP path", want["MPJPE"], "mm, oracle path", ref_path["MPJPE"], "mm, difference",
           abs(want["MPJPE"] - ref_path["MPJPE"]), "mm")
     assert abs(want["MPJPE"] - ref_path["MPJPE"]) < 1e-3
+    # the throughput mode of bench.py (fp16 weight image, fp16 VAE operands) on the same inputs: measured and reported,
+    # not held to the fp32 gate
+    model.denoiser.weight_dtype = "fp16"
+    model.vae.precision = "fp16"
+    rs16 = model.ego_eval(batch, latents=lat)
+    m16 = O.ego_metrics(rs16["joints_rst"].double().cpu().numpy(), rs16["joints_ref"].double().cpu().numpy(),
+                        rs16["orientation_quat_rst"].double().cpu().numpy(), rs16["orientation_quat_ref"].double().cpu().numpy(),
+                        rs16["lengths"], "val")
+    between16 = float(np.linalg.norm(rs16["joints_rst"].cpu().numpy() - j, axis=-1).mean() * 1000.0)
+    print("fp16 mode: MPJPE vs ground truth", m16["MPJPE"], "mm (oracle path", ref_path["MPJPE"], "mm), difference",
+          abs(m16["MPJPE"] - ref_path["MPJPE"]), "mm; joint-to-joint distance to the oracle path", between16, "mm")
+    assert between16 < 5.0
 
 
 def test_autograd_twin_matches_hip(dev):
