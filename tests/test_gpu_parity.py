@@ -613,6 +613,31 @@ def test_vae_fp16_mfma_mode(dev):
         assert e_mu < 2e-2 and e_dec < 2e-2
 
 
+def test_vae_long_ragged_sequences_fp16_vs_fp32_vs_oracle(dev):
+    """Sequences longer than one 256-key chunk (S = T + 2 = 302 -> two score chunks, 8 score columns per lane in the
+    register softmax) with ragged lengths: fp32 path against the oracle (1e-4), fp16 path against the fp32 path."""
+    from seeme_amd.mld_vae import MldVae
+    F_, T = 75, 300
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((3, T, F_)).astype(np.float32)
+    lengths = [300, 257, 64]
+    P = recipe_state_dict(shapes.vae_shapes(F_))
+    vae = load_recipe_(MldVae(ablation(), nfeats=F_, latent_dim=[1, 256], arch="encoder_decoder")).to(dev).eval()
+    _, d32 = vae.encode(torch.from_numpy(x).to(dev), None, lengths)
+    mu_o, std_o = O.vae_encode(P, x, lengths)
+    assert rel_err(d32.loc.cpu().numpy(), mu_o) < TOL_F32 and rel_err(d32.scale.cpu().numpy(), std_o) < TOL_F32
+    dec32 = vae.decode(d32.loc, lengths)
+    dec_o = O.vae_decode(P, mu_o, lengths)
+    for b, Lb in enumerate(lengths):                 # frames past a sequence's length are unspecified (mld_vae.py:253)
+        assert rel_err(dec32[b, :Lb].cpu().numpy(), dec_o[b, :Lb]) < TOL_F32
+    vae.precision = "fp16"
+    _, d16 = vae.encode(torch.from_numpy(x).to(dev), None, lengths)
+    dec16 = vae.decode(d32.loc, lengths)
+    assert rel_err(d16.loc.cpu().numpy(), d32.loc.cpu().numpy()) < 2e-2
+    for b, Lb in enumerate(lengths):
+        assert rel_err(dec16[b, :Lb].cpu().numpy(), dec32[b, :Lb].cpu().numpy()) < 2e-2
+
+
 # ----------------------------------------------------------------------------- train.py / test.py equivalents
 @pytest.mark.gpu
 def test_cli_train_resume_and_test(dev, tmp_path):
