@@ -361,14 +361,20 @@ static int launch_linear_h(const LinearHArgs& ha, hipStream_t st) {
 // 32-row tile: 4x fewer re-reads of the 128 KB weight chunk from L2, two waves per SIMD, no fp32 staging or epilogue
 // tile (the fp16 output tile reuses the operand tile's LDS).
 #define QKV_MT 128
+// ALL3 = false: grid (row tiles, 3), a workgroup produces one of q | k | v for its 128 rows -- three times as many
+// workgroups for the small launches, which are latency-bound.  ALL3 = true: grid (row tiles), q, k and v from ONE staged
+// operand tile -- at large batch the kernel is HBM-bound (B=512: 460 MB per launch at 4 TB/s) and two thirds of its reads
+// were the same fp32 rows fetched by the three column blocks.
+template <bool ALL3>
 __global__ __launch_bounds__(512) void k_qkv_h(const LinearHArgs ha) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const SeemeLinearArgs& a = ha.k.a;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int mh = wave >> 2, nq = wave & 3;
     constexpr int LDH = 256 + HPAD;
-    unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);            // [128][272] fp16 operand tile, later the output tile
-    const int m0 = blockIdx.x * QKV_MT, y = blockIdx.y;
+    unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);            // [128][272] fp16 operand tile (ALL3 = false: later the output tile)
+    unsigned short* Oh = ALL3 ? Ah + QKV_MT * LDH : Ah;                      // output tile
+    const int m0 = blockIdx.x * QKV_MT;
     H16_DBG(4, 0);
     {   // stage: 128 rows x 64 float4, all of a thread's loads in flight together
         constexpr int NIT = QKV_MT * 64 / 512;
@@ -390,40 +396,52 @@ __global__ __launch_bounds__(512) void k_qkv_h(const LinearHArgs ha) {
     }
     __syncthreads();
     H16_DBG(4, 1);
-    f32x4 acc[4][4];
-    acc_zero(acc);
-    const BiasRegs<4> bias = bias_load<4>(a.bias, y * 256 + nq * 64, 768);
-    gemm_packed<4, 4>(Ah + mh * 64 * LDH, LDH, ha.wp, ha.kstride, y * 16 + nq * 4, ha.ntiles, 8, acc);
-    H16_DBG(4, 2);
-    __syncthreads();                                                          // operand tile consumed: it becomes the output tile
-    acc_store_h16<4, 4>(acc, Ah + mh * 64 * LDH, LDH, nq * 64, bias, SEEME_ACT_NONE);
-    __syncthreads();
-    H16_DBG(4, 3);
-    if (y < 2) {            // q | k: fp16 rows, 16-byte coalesced stores
-        for (int idx = tid; idx < QKV_MT * 32; idx += 512) {
-            const int row = idx >> 5, c8 = (idx & 31) * 8, m = m0 + row;
-            if (m < a.M) *reinterpret_cast<uint4*>(ha.qk + (size_t)m * 512 + y * 256 + c8) = *reinterpret_cast<const uint4*>(Ah + row * LDH + c8);
-        }
-    } else {                // v -> transposed [b][d][s]: lanes <-> rows (consecutive s), loop over d
-        const int row = tid & 127, dg = tid >> 7, m = m0 + row;
-        if (m < a.M) {
-            const int b = m / ha.S, s2 = m - b * ha.S;
-            unsigned short* base = ha.vt + ((size_t)b * 256) * ha.spv + s2;
+    for (int y = ALL3 ? 0 : (int)blockIdx.y; y < (ALL3 ? 3 : (int)blockIdx.y + 1); ++y) {
+        f32x4 acc[4][4];
+        acc_zero(acc);
+        const BiasRegs<4> bias = bias_load<4>(a.bias, y * 256 + nq * 64, 768);
+        gemm_packed<4, 4>(Ah + mh * 64 * LDH, LDH, ha.wp, ha.kstride, y * 16 + nq * 4, ha.ntiles, 8, acc);
+        H16_DBG(4, 2);
+        __syncthreads();                                                      // ALL3 = false: operand tile consumed, it becomes the output tile;
+                                                                              // ALL3 = true: the previous part's stores have read the output tile
+        acc_store_h16<4, 4>(acc, Oh + mh * 64 * LDH, LDH, nq * 64, bias, SEEME_ACT_NONE);
+        __syncthreads();
+        H16_DBG(4, 3);
+        if (y < 2) {            // q | k: fp16 rows, 16-byte coalesced stores
+            for (int idx = tid; idx < QKV_MT * 32; idx += 512) {
+                const int row = idx >> 5, c8 = (idx & 31) * 8, m = m0 + row;
+                if (m < a.M) *reinterpret_cast<uint4*>(ha.qk + (size_t)m * 512 + y * 256 + c8) = *reinterpret_cast<const uint4*>(Oh + row * LDH + c8);
+            }
+        } else {                // v -> transposed [b][d][s]: lanes <-> rows (consecutive s), loop over d
+            const int row = tid & 127, dg = tid >> 7, m = m0 + row;
+            if (m < a.M) {
+                const int b = m / ha.S, s2 = m - b * ha.S;
+                unsigned short* base = ha.vt + ((size_t)b * 256) * ha.spv + s2;
 #pragma unroll 8
-            for (int j = 0; j < 64; ++j) {
-                const int d = dg * 64 + j;
-                base[(size_t)d * ha.spv] = Ah[row * LDH + d];
+                for (int j = 0; j < 64; ++j) {
+                    const int d = dg * 64 + j;
+                    base[(size_t)d * ha.spv] = Oh[row * LDH + d];
+                }
             }
         }
     }
     H16_DBG(4, 4);
 }
+#ifndef QKV_ALL3_TILES
+#define QKV_ALL3_TILES 256   // from this many 128-row tiles on (one per CU), q | k | v come from one staged operand tile
+#endif
 static int launch_qkv_h(const LinearHArgs& ha, hipStream_t st) {
     const SeemeLinearArgs& a = ha.k.a;
-    const size_t lds = (size_t)QKV_MT * (256 + HPAD) * 2;
-    dim3 grid((a.M + QKV_MT - 1) / QKV_MT, 3);
-    SEEME_HIP(hipFuncSetAttribute((const void*)k_qkv_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_qkv_h, grid, dim3(512), lds, st, ha);
+    const int tiles = (a.M + QKV_MT - 1) / QKV_MT;
+    if (tiles >= QKV_ALL3_TILES) {
+        const size_t lds = (size_t)2 * QKV_MT * (256 + HPAD) * 2;
+        SEEME_HIP(hipFuncSetAttribute((const void*)k_qkv_h<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_qkv_h<true>, dim3(tiles), dim3(512), lds, st, ha);
+    } else {
+        const size_t lds = (size_t)QKV_MT * (256 + HPAD) * 2;
+        SEEME_HIP(hipFuncSetAttribute((const void*)k_qkv_h<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_qkv_h<false>, dim3(tiles, 3), dim3(512), lds, st, ha);
+    }
     return seeme_check_launch("k_qkv_h");
 }
 

@@ -638,6 +638,25 @@ def test_vae_long_ragged_sequences_fp16_vs_fp32_vs_oracle(dev):
         assert rel_err(dec16[b, :Lb].cpu().numpy(), dec32[b, :Lb].cpu().numpy()) < 2e-2
 
 
+def test_vae_fp16_large_batch_matches_small_batch(dev):
+    """From 256 row tiles on (B >= 167 at T=196) the fp16 QKV projection takes q, k and v from one staged operand tile
+    instead of three workgroups per tile: the same sequences must come out BIT-identical in a large and a small batch
+    (per-row arithmetic does not depend on the partition), and close to the fp32 path."""
+    from seeme_amd.mld_vae import MldVae
+    F_, T, B = 75, 196, 176
+    rng = np.random.default_rng(33)
+    x = torch.from_numpy(rng.standard_normal((B, T, F_)).astype(np.float32)).to(dev)
+    lengths = [T] * B
+    vae = load_recipe_(MldVae(ablation(), nfeats=F_, latent_dim=[1, 256], arch="encoder_decoder", precision="fp16")).to(dev).eval()
+    big = vae.encode_dist(x, lengths)                                    # [2,B,256]
+    idx = [0, 57, 175]
+    small = vae.encode_dist(x[idx].contiguous(), [T] * len(idx))
+    assert torch.equal(big[:, idx], small)
+    vae.precision = "fp32"
+    ref = vae.encode_dist(x[idx].contiguous(), [T] * len(idx))
+    assert rel_err(small.cpu().numpy(), ref.cpu().numpy()) < 2e-2
+
+
 # ----------------------------------------------------------------------------- train.py / test.py equivalents
 @pytest.mark.gpu
 def test_cli_train_resume_and_test(dev, tmp_path):
