@@ -32,17 +32,25 @@ __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
     // ---- stage A tile (zero padded), optional pre-LN and pre-activation
     const bool a_vec = (a.A2 == nullptr) && ((a.K & 3) == 0) && ((a.lda & 3) == 0) && ((reinterpret_cast<size_t>(a.A) & 15) == 0);
     if (a_vec) {   // float4 path: K/4 vectors per row, rows spread over the 256 threads
-        const int K4 = a.K >> 2, Kp4 = Kp >> 2;
-        for (int idx = tid; idx < TILE_M * Kp4; idx += 256) {
-            const int row = idx / Kp4, c4 = idx - row * Kp4;
-            const int m = m0 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < a.M && c4 < K4) {
-                int prow = m;
-                if (ka.seq_in > 0) prow = (m / ka.seq_in) * ka.in_stride + (m % ka.seq_in) + ka.in_off;
-                v = *reinterpret_cast<const float4*>(a.A + (size_t)prow * a.lda + 4 * c4);
+        // batches of 8 guarded loads per thread, all issued before the first is stored (guard = select on address and
+        // value; a branch per load made every load a full round trip)
+        const int K4 = a.K >> 2, Kp4 = Kp >> 2, total = TILE_M * Kp4;
+        for (int base = 0; base < total; base += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = base + tid + j * 256, row = idx / Kp4, c4 = idx - row * Kp4, m = m0 + row;
+                const bool valid = idx < total && m < a.M && c4 < K4;
+                int prow = valid ? m : 0;
+                if (ka.seq_in > 0) prow = (prow / ka.seq_in) * ka.in_stride + (prow % ka.seq_in) + ka.in_off;
+                v[j] = *reinterpret_cast<const float4*>(valid ? a.A + (size_t)prow * a.lda + 4 * c4 : a.A);
+                if (!valid) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            *reinterpret_cast<float4*>(As + row * lda_s + 4 * c4) = v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = base + tid + j * 256, row = idx / Kp4, c4 = idx - row * Kp4;
+                if (idx < total) *reinterpret_cast<float4*>(As + row * lda_s + 4 * c4) = v[j];
+            }
         }
     } else {
         for (int idx = tid; idx < TILE_M * Kp; idx += 256) {
@@ -90,6 +98,25 @@ __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
 
     // ---- row pass: residual, LayerNorm, coalesced store.  wave w -> rows 8w..8w+7, lane -> 4 cols
     const bool vec_ok = ((a.ldy & 3) == 0) && ((a.N & 3) == 0);
+    // residual rows as float4, all 8 of the wave requested together (when rows are 16-byte aligned and whole); LayerNorm
+    // parameters once per phase
+    const bool res_vec = a.res != nullptr && ((a.ldr & 3) == 0) && ((a.N & 3) == 0) && ((reinterpret_cast<size_t>(a.res) & 15) == 0);
+    const LnParams lp = ln_params256(a.ln_w, a.ln_b);
+    float4 rv[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        rv[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res_vec) {
+            const int m = m0 + wave * 8 + rr, mc = m < a.M ? m : 0, g = cn0 + lane * 4;
+            int orow = mc;
+            if (ka.seq_in > 0) orow = (mc / ka.seq_in) * ka.out_stride + (mc % ka.seq_in) + ka.out_off;
+            const size_t rrow = ka.res_mode == 1 ? (size_t)((mc % ka.seq_in) + ka.res_off)
+                              : ka.res_mode == 2 ? (size_t)(mc / ka.seq_in) : (size_t)orow;
+            rv[rr] = *reinterpret_cast<const float4*>(a.res + rrow * a.ldr + (g + 3 < a.N ? g : 0));
+            if (g + 3 >= a.N) rv[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
         const int row = wave * 8 + rr;
         const int m = m0 + row;
@@ -98,7 +125,9 @@ __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
         if (ka.seq_in > 0) orow = (m / ka.seq_in) * ka.out_stride + (m % ka.seq_in) + ka.out_off;
         const int c = lane * 4, g = cn0 + c;
         float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + c);
-        if (a.res != nullptr) {
+        if (res_vec) {
+            v = make_float4(v.x + rv[rr].x, v.y + rv[rr].y, v.z + rv[rr].z, v.w + rv[rr].w);
+        } else if (a.res != nullptr) {
             const size_t rrow = ka.res_mode == 1 ? (size_t)((m % ka.seq_in) + ka.res_off)
                               : ka.res_mode == 2 ? (size_t)(m / ka.seq_in) : (size_t)orow;
             const float* rp = a.res + rrow * a.ldr + g;
@@ -107,7 +136,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
             if (g + 2 < a.N) v.z += rp[2];
             if (g + 3 < a.N) v.w += rp[3];
         }
-        if (a.ln_w != nullptr) v = wave_layernorm256(v, a.ln_w, a.ln_b, a.eps);  // N == 256, cn0 == 0
+        if (a.ln_w != nullptr) v = wave_layernorm256(v, lp, a.eps);  // N == 256, cn0 == 0
         float* yp = a.Y + (size_t)orow * a.ldy + g;
         if (vec_ok && g + 3 < a.N) {
             *reinterpret_cast<float4*>(yp) = v;
@@ -178,6 +207,35 @@ struct AttnKArgs {
     float eps;
 };
 
+template <int NC>      // NC = Sp / 64 score columns per lane
+__device__ __forceinline__ void attn_softmax_rows_f32(float* Ps, int ldp, int wave, int lane) {
+    float v[8][NC], mx[8], sum[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const float* prow = Ps + (wave * 8 + rr) * ldp + lane;
+        mx[rr] = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { v[rr][j] = prow[64 * j]; mx[rr] = fmaxf(mx[rr], v[rr][j]); }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) mx[rr] = wave_max(mx[rr]);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        sum[rr] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { v[rr][j] = expf(v[rr][j] - mx[rr]); sum[rr] += v[rr][j]; }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) sum[rr] = wave_sum(sum[rr]);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const float inv = 1.f / sum[rr];
+        float* prow = Ps + (wave * 8 + rr) * ldp + lane;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) prow[64 * j] = v[rr][j] * inv;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_attn_block(const AttnKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
@@ -196,12 +254,20 @@ __global__ __launch_bounds__(256) void k_attn_block(const AttnKArgs a) {
     const size_t base = (size_t)b * a.S;
     const int n_valid_keys = min(a.S, a.n_prefix + a.lengths[b]);
 
-    for (int idx = tid; idx < TILE_M * 64; idx += 256) {  // Q tile, float4 per thread
-        const int row = idx >> 6, c4 = (idx & 63) * 4;
-        const int s = q0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s < a.q_rows) v = *reinterpret_cast<const float4*>(a.qkv + (base + s) * 768 + c4);
-        *reinterpret_cast<float4*>(Qs + row * ldq + c4) = v;
+    {   // Q tile, 8 float4 per thread requested together (the guard is a select on address and value: written as a branch
+        // per load the compiler waits for every load before issuing the next -- eight serialised round trips)
+        float4 qv[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = tid + it * 256, row = idx >> 6, c4 = (idx & 63) * 4, s = q0 + row;
+            qv[it] = *reinterpret_cast<const float4*>(a.qkv + (base + (s < a.q_rows ? s : 0)) * 768 + c4);
+            if (s >= a.q_rows) qv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = tid + it * 256, row = idx >> 6, c4 = (idx & 63) * 4;
+            *reinterpret_cast<float4*>(Qs + row * ldq + c4) = qv[it];
+        }
     }
     __syncthreads();
 
@@ -226,16 +292,10 @@ __global__ __launch_bounds__(256) void k_attn_block(const AttnKArgs a) {
     __syncthreads();
 
     // ---- softmax over keys, wave w -> rows 8w..8w+7
-    for (int rr = 0; rr < 8; ++rr) {
-        float* prow = Ps + (wave * 8 + rr) * ldp;
-        float mx = -INFINITY;
-        for (int c = lane; c < a.Sp; c += 64) mx = fmaxf(mx, prow[c]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int c = lane; c < a.Sp; c += 64) { const float e = expf(prow[c] - mx); prow[c] = e; sum += e; }
-        const float inv = 1.f / wave_sum(sum);
-        for (int c = lane; c < a.Sp; c += 64) prow[c] *= inv;
-    }
+    // (the wave's 8 rows are held in registers and reduced together: same per-row arithmetic and summation order as
+    // the row-by-row loop, without its 16 dependent reductions in sequence)
+    if (a.Sp == 256) attn_softmax_rows_f32<4>(Ps, ldp, wave, lane);
+    else attn_softmax_rows_f32<8>(Ps, ldp, wave, lane);
     __syncthreads();
 
     // ---- O = P V   (contraction over keys; P is exactly 0 beyond n_valid_keys)
@@ -260,15 +320,23 @@ __global__ __launch_bounds__(256) void k_attn_block(const AttnKArgs a) {
         acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, a.bo, 0, 256, SEEME_ACT_NONE);
     }
     __syncthreads();
-    for (int rr = 0; rr < 8; ++rr) {
-        const int row = wave * 8 + rr, s = q0 + row;
-        if (s >= a.q_rows) continue;
-        const size_t g = (base + s) * 256 + lane * 4;
-        float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + lane * 4);
-        const float4 x = *reinterpret_cast<const float4*>(a.res + g);
-        v = make_float4(v.x + x.x, v.y + x.y, v.z + x.z, v.w + x.w);
-        v = wave_layernorm256(v, a.ln_w, a.ln_b, a.eps);
-        *reinterpret_cast<float4*>(a.out + g) = v;
+    {   // residual rows and LayerNorm parameters requested together, then one pass of LN + store per row
+        const LnParams lp = ln_params256(a.ln_w, a.ln_b);
+        float4 xr[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int s = q0 + wave * 8 + rr;
+            xr[rr] = *reinterpret_cast<const float4*>(a.res + (base + (s < a.q_rows ? s : 0)) * 256 + lane * 4);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr, s = q0 + row;
+            if (s >= a.q_rows) continue;
+            float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + lane * 4);
+            v = make_float4(v.x + xr[rr].x, v.y + xr[rr].y, v.z + xr[rr].z, v.w + xr[rr].w);
+            v = wave_layernorm256(v, lp, a.eps);
+            *reinterpret_cast<float4*>(a.out + (base + s) * 256 + lane * 4) = v;
+        }
     }
 }
 
@@ -312,20 +380,29 @@ __global__ __launch_bounds__(256) void k_ffn_block(const FfnKArgs a) {
     float* Hs = smem + TILE_M * ld;   // [32][264] hidden chunk, later the output tile
     const int m0 = blockIdx.x * TILE_M;
 
-    for (int rr = 0; rr < 8; ++rr) {  // wave w stages rows 8w..8w+7 (one float4 per lane)
-        const int row = wave * 8 + rr, m = m0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < a.M) {
-            const int seq = m / a.seq_rows;
-            const size_t prow = (size_t)seq * a.seq_stride + (m % a.seq_rows);
-            v = *reinterpret_cast<const float4*>(a.x + prow * 256 + lane * 4);
-            if (a.cvec != nullptr) {
-                const float4 c = *reinterpret_cast<const float4*>(a.cvec + (size_t)seq * a.cvec_ld + lane * 4);
-                v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
-                v = wave_layernorm256(v, a.lnc_w, a.lnc_b, a.eps);
-            }
+    {   // wave w stages rows 8w..8w+7 (one float4 per lane): rows and cross-attention vectors requested together
+        float4 xv[8], cv[8];
+        const LnParams lc = ln_params256(a.lnc_w, a.lnc_b);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int m = m0 + wave * 8 + rr, mc = m < a.M ? m : 0;
+            const int seq = mc / a.seq_rows;
+            const size_t prow = (size_t)seq * a.seq_stride + (mc % a.seq_rows);
+            xv[rr] = *reinterpret_cast<const float4*>(a.x + prow * 256 + lane * 4);
+            cv[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.cvec != nullptr) cv[rr] = *reinterpret_cast<const float4*>(a.cvec + (size_t)seq * a.cvec_ld + lane * 4);
         }
-        *reinterpret_cast<float4*>(Xs + row * ld + lane * 4) = v;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr, m = m0 + row;
+            float4 v = xv[rr];
+            if (a.cvec != nullptr) {
+                v = make_float4(v.x + cv[rr].x, v.y + cv[rr].y, v.z + cv[rr].z, v.w + cv[rr].w);
+                v = wave_layernorm256(v, lc, a.eps);
+            }
+            if (m >= a.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(Xs + row * ld + lane * 4) = v;
+        }
     }
     __syncthreads();
 
@@ -351,14 +428,15 @@ __global__ __launch_bounds__(256) void k_ffn_block(const FfnKArgs a) {
     acc_store_lds<2, 4>(acc2, Hs, ld, wave * 64, a.b2, 0, 256, SEEME_ACT_NONE);
     __syncthreads();
 
+    const LnParams lp = ln_params256(a.ln_w, a.ln_b), lf = ln_params256(a.fin_w, a.fin_b);
     for (int rr = 0; rr < 8; ++rr) {
         const int row = wave * 8 + rr, m = m0 + row;
         if (m >= a.M) continue;
         float4 v = *reinterpret_cast<const float4*>(Hs + row * ld + lane * 4);
         const float4 x = *reinterpret_cast<const float4*>(Xs + row * ld + lane * 4);
         v = make_float4(v.x + x.x, v.y + x.y, v.z + x.z, v.w + x.w);
-        v = wave_layernorm256(v, a.ln_w, a.ln_b, a.eps);
-        if (a.fin_w != nullptr) v = wave_layernorm256(v, a.fin_w, a.fin_b, a.eps);
+        v = wave_layernorm256(v, lp, a.eps);
+        if (a.fin_w != nullptr) v = wave_layernorm256(v, lf, a.eps);
         const int seq = m / a.seq_rows, sr = m % a.seq_rows;
         size_t orow = (size_t)seq * a.seq_stride + sr;
         if (a.out_mode == 1) orow = (size_t)sr * (a.M / a.seq_rows) + seq;
