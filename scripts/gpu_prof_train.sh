@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out
 rm -rf gpurun_out/prof_train
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -- python scripts/train_step_bench.py --steps 2 --scene-precision ${1:-bf16} > gpurun_out/prof_train.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -- python scripts/train_breakdown.py vae16 > gpurun_out/prof_train.log 2>&1
 python - <<PY
 import csv, glob, collections
 f = glob.glob('gpurun_out/prof_train/*/*kernel_stats.csv')[0]
