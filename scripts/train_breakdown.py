@@ -86,3 +86,25 @@ if "proffwd" in sys.argv[1:]:
     print("backward device kernels:", sum(v[0] for v in agg.values()), "total us", round(sum(v[1] for v in agg.values()), 1))
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
         print(f"  {v[1]:8.1f} us {v[0]:4d}x {k}")
+
+if "lines" in sys.argv[1:]:
+    import collections
+    from torch.profiler import profile, ProfilerActivity
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        rs = model.train_diffusion_forward(batch)
+        loss = model.losses["train"].update(rs)
+        model.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        model.optimizer_update()
+        torch.cuda.synchronize()
+    # CPU-side op events carry the Python stack; attribute every launch (cuda_time of the op) to the innermost repo frame
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for e in prof.events():
+        if e.device_type.name == "CPU" and e.stack and e.device_time > 0 and not e.cpu_children:
+            fr = [s for s in e.stack if "/seeme_amd/" in s or "train_breakdown" in s]
+            key = fr[0].split("/")[-1][:70] if fr else "(autograd engine / other)"
+            agg[key][0] += 1; agg[key][1] += e.device_time
+    print("leaf ops with device time, by innermost repo frame:")
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+        print(f"  {v[1]:8.1f} us {v[0]:4d} ops  {k}")

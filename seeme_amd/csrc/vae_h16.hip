@@ -46,20 +46,29 @@ extern "C" int seeme_debug_h16_times(unsigned long long* host, int n) {
 #ifndef FFN_PF
 #define FFN_PF H16_PF  // the FFN's first GEMM (2 n-tiles per wave)
 #endif
+// The first PF k-blocks of a GEMM's B fragments, requested EARLY -- at kernel start, next to the activation rows -- so
+// that the cold miss of the weights (every launch finds them evicted from its XCD's L2 by the sampling kernel's 9 MB
+// stream) overlaps the staging phase instead of following it.
+template <int NTL, int PF>
+struct BRing { uint4 br[PF][NTL]; };
+template <int NTL, int PF, typename LoadB>
+__device__ __forceinline__ void ring_prime(BRing<NTL, PF>& ring, int K32, LoadB loadb) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) ring.br[u][nt] = loadb(nt, u < K32 ? u : K32 - 1);
+}
+
 template <int MTL, int NTL, int PF, typename LoadB>
 __device__ __forceinline__ void tile_gemm_h16(const unsigned short* __restrict__ As, int lda, int K32, LoadB loadb,
-                                              f32x4 (&acc)[MTL][NTL]) {
+                                              f32x4 (&acc)[MTL][NTL], BRing<NTL, PF>& ring) {
     static_assert(PF % 2 == 0, "A-fragment ping-pong follows the slot parity");
     const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
     const unsigned short* ap = As + r * lda + 8 * kq;
     // PF k-blocks of B fragments in flight; a slot is re-filled right after the MFMAs that read it.  The scheduler is
     // fenced per k-block: left alone it sinks the re-fills to just before their use (a vmcnt(0) per k-block) and the
     // pipeline collapses -- these tiles are latency-bound, the depth of this pipeline is their speed.
-    uint4 br[PF][NTL];
-#pragma unroll
-    for (int u = 0; u < PF; ++u)
-#pragma unroll
-        for (int nt = 0; nt < NTL; ++nt) br[u][nt] = loadb(nt, u < K32 ? u : K32 - 1);
+    uint4 (&br)[PF][NTL] = ring.br;                          // primed by the caller (ring_prime)
     uint4 ab[2][MTL];
 #pragma unroll
     for (int mt = 0; mt < MTL; ++mt) ab[0][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda);
@@ -89,22 +98,40 @@ __device__ __forceinline__ void tile_gemm_h16(const unsigned short* __restrict__
 // B fragments from fragment-packed weights: Wp[(ntile*kstride + kb)*64 + lane]; n-tiles clamped to ntiles-1
 template <int MTL, int NTL, int PF = H16_PF>
 __device__ __forceinline__ void gemm_packed(const unsigned short* As, int lda, const uint4* __restrict__ Wp, int kstride,
-                                            int ntile0, int ntiles, int K32, f32x4 (&acc)[MTL][NTL]) {
+                                            int ntile0, int ntiles, int K32, f32x4 (&acc)[MTL][NTL], BRing<NTL, PF>& ring) {
     const int lane = threadIdx.x & 63;
     tile_gemm_h16<MTL, NTL, PF>(As, lda, K32, [&](int nt, int kb) {
         int t = ntile0 + nt; t = t < ntiles ? t : ntiles - 1;
         return Wp[((size_t)t * kstride + kb) * 64 + lane];
-    }, acc);
+    }, acc, ring);
+}
+template <int NTL, int PF = H16_PF>
+__device__ __forceinline__ void prime_packed(BRing<NTL, PF>& ring, const uint4* __restrict__ Wp, int kstride, int ntile0, int ntiles, int K32) {
+    const int lane = threadIdx.x & 63;
+    ring_prime(ring, K32, [&](int nt, int kb) {
+        int t = ntile0 + nt; t = t < ntiles ? t : ntiles - 1;
+        return Wp[((size_t)t * kstride + kb) * 64 + lane];
+    });
+}
+template <int MTL, int NTL, int PF = H16_PF>
+__device__ __forceinline__ void gemm_packed(const unsigned short* As, int lda, const uint4* __restrict__ Wp, int kstride,
+                                            int ntile0, int ntiles, int K32, f32x4 (&acc)[MTL][NTL]) {
+    BRing<NTL, PF> ring;
+    prime_packed(ring, Wp, kstride, ntile0, ntiles, K32);
+    gemm_packed<MTL, NTL, PF>(As, lda, Wp, kstride, ntile0, ntiles, K32, acc, ring);
 }
 // B fragments from a row-major fp16 matrix Bm[n][k] (rows clamped to n_valid-1)
 template <int MTL, int NTL, int PF = H16_PF>
 __device__ __forceinline__ void gemm_rows(const unsigned short* As, int lda, const unsigned short* __restrict__ Bm, int ldb,
                                           int n0, int n_valid, int K32, f32x4 (&acc)[MTL][NTL]) {
     const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
-    tile_gemm_h16<MTL, NTL, PF>(As, lda, K32, [&](int nt, int kb) {
+    auto loadb = [&](int nt, int kb) {
         int n = n0 + nt * 16 + r; n = n < n_valid ? n : n_valid - 1;
         return *reinterpret_cast<const uint4*>(Bm + (size_t)n * ldb + kb * 32 + 8 * kq);
-    }, acc);
+    };
+    BRing<NTL, PF> ring;
+    ring_prime(ring, K32, loadb);
+    tile_gemm_h16<MTL, NTL, PF>(As, lda, K32, loadb, acc, ring);
 }
 // accumulators -> fp16 LDS tile (the next GEMM's A operand), + bias, activation
 template <int MTL, int NTL>
@@ -164,6 +191,10 @@ __global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
     const int ldc = CH_N + LDS_PAD;
     const int m0 = blockIdx.x * TILE_M, cn0 = blockIdx.y * CH_N;
     H16_DBG(2, 0);
+    const int n0 = cn0 + wave * 64;
+    const BiasRegs<4> bias = bias_load<4>(a.bias, n0, a.N);
+    BRing<4, H16_PF> ring;
+    if (n0 < a.N) prime_packed(ring, ha.wp, ha.kstride, n0 >> 4, ha.ntiles, Kp >> 5);
 
     if (ha.fast == 1) {   // float4 in, 4 halves out, no fp32 staging tile
         // Batches of 8 guarded loads per thread, ALL issued before the first is converted.  Written as
@@ -256,9 +287,7 @@ __global__ __launch_bounds__(256) void k_linear_h(const LinearHArgs ha) {
     H16_DBG(2, 1);
     f32x4 acc[2][4];
     acc_zero(acc);
-    const int n0 = cn0 + wave * 64;
-    const BiasRegs<4> bias = bias_load<4>(a.bias, n0, a.N);
-    if (n0 < a.N) gemm_packed<2, 4>(Ah, lda_h, ha.wp, ha.kstride, n0 >> 4, ha.ntiles, Kp >> 5, acc);
+    if (n0 < a.N) gemm_packed<2, 4>(Ah, lda_h, ha.wp, ha.kstride, n0 >> 4, ha.ntiles, Kp >> 5, acc, ring);
     H16_DBG(2, 2);
     acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, bias, a.act);
     __syncthreads();
@@ -375,6 +404,9 @@ __global__ __launch_bounds__(512) void k_qkv_h(const LinearHArgs ha) {
     unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);            // [128][272] fp16 operand tile (ALL3 = false: later the output tile)
     unsigned short* Oh = ALL3 ? Ah + QKV_MT * LDH : Ah;                      // output tile
     const int m0 = blockIdx.x * QKV_MT;
+    const int y_begin = ALL3 ? 0 : (int)blockIdx.y, y_end = ALL3 ? 3 : (int)blockIdx.y + 1;
+    BRing<4, H16_PF> ring;                                                   // weights of the first part, requested next to the rows
+    prime_packed(ring, ha.wp, ha.kstride, y_begin * 16 + nq * 4, ha.ntiles, 8);
     H16_DBG(4, 0);
     {   // stage: 128 rows x 64 float4, all of a thread's loads in flight together
         constexpr int NIT = QKV_MT * 64 / 512;
@@ -396,11 +428,12 @@ __global__ __launch_bounds__(512) void k_qkv_h(const LinearHArgs ha) {
     }
     __syncthreads();
     H16_DBG(4, 1);
-    for (int y = ALL3 ? 0 : (int)blockIdx.y; y < (ALL3 ? 3 : (int)blockIdx.y + 1); ++y) {
+    for (int y = y_begin; y < y_end; ++y) {
         f32x4 acc[4][4];
         acc_zero(acc);
         const BiasRegs<4> bias = bias_load<4>(a.bias, y * 256 + nq * 64, 768);
-        gemm_packed<4, 4>(Ah + mh * 64 * LDH, LDH, ha.wp, ha.kstride, y * 16 + nq * 4, ha.ntiles, 8, acc);
+        gemm_packed<4, 4>(Ah + mh * 64 * LDH, LDH, ha.wp, ha.kstride, y * 16 + nq * 4, ha.ntiles, 8, acc, ring);
+        if (y + 1 < y_end) prime_packed(ring, ha.wp, ha.kstride, (y + 1) * 16 + nq * 4, ha.ntiles, 8);   // under this part's stores
         H16_DBG(4, 2);
         __syncthreads();                                                      // ALL3 = false: operand tile consumed, it becomes the output tile;
                                                                               // ALL3 = true: the previous part's stores have read the output tile
@@ -509,6 +542,9 @@ __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
     const size_t base = (size_t)b * a.S;
     const int n_valid_keys = min(a.S, a.n_prefix + a.lengths[b]);
     H16_DBG(1, 0);
+    const BiasRegs<4> bias_o = bias_load<4>(a.bo, wave * 64, 256);
+    BRing<4, ATT_PF> ring_o;
+    prime_packed(ring_o, a.wo, 8, wave * 4, 16, 8);
 
     {   // Q tile, 8 halves per thread x 4, requested together (guard = select on address and value, no branch per load)
         uint4 qv[4];
@@ -565,9 +601,8 @@ __global__ __launch_bounds__(256) void k_attn_block_h(const AttnHArgs a) {
     {
         f32x4 acc[2][4];
         acc_zero(acc);
-        const BiasRegs<4> bias = bias_load<4>(a.bo, wave * 64, 256);
-        gemm_packed<2, 4, ATT_PF>(Qh, ldq, a.wo, 8, wave * 4, 16, 8, acc);
-        acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, bias, SEEME_ACT_NONE);
+        gemm_packed<2, 4, ATT_PF>(Qh, ldq, a.wo, 8, wave * 4, 16, 8, acc, ring_o);
+        acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, bias_o, SEEME_ACT_NONE);
     }
     __syncthreads();
     H16_DBG(1, 5);
@@ -627,6 +662,10 @@ __global__ __launch_bounds__(256) void k_ffn_block_h(const FfnHArgs a) {
     const int m0 = blockIdx.x * TILE_M;
     const BiasRegs<2> bias1 = bias_load<2>(a.b1, wave * 32, a.FF);
     const BiasRegs<4> bias2 = bias_load<4>(a.b2, wave * 64, 256);
+    BRing<2, FFN_PF> ring1;
+    BRing<4, H16_PF> ring2;
+    prime_packed(ring1, a.w1, 8, wave * 2, a.FF >> 4, 8);
+    prime_packed(ring2, a.w2, a.FF >> 5, wave * 4, 16, a.FF >> 5);
     H16_DBG(3, 0);
     {   // the wave's 8 rows (and their cross-attention vectors) are requested together, then normalised / converted
         float4 xv[8], cv[8];
@@ -661,7 +700,7 @@ __global__ __launch_bounds__(256) void k_ffn_block_h(const FfnHArgs a) {
     {   // hidden = act(W1 x + b1): FF = 128 -> 32 columns per wave
         f32x4 acc1[2][2];
         acc_zero(acc1);
-        gemm_packed<2, 2, FFN_PF>(Xh, ldh, a.w1, 8, wave * 2, a.FF >> 4, 8, acc1);
+        gemm_packed<2, 2, FFN_PF>(Xh, ldh, a.w1, 8, wave * 2, a.FF >> 4, 8, acc1, ring1);
         acc_store_h16<2, 2>(acc1, Hh, ldhh, wave * 32, bias1, a.act);
     }
     __syncthreads();
@@ -669,7 +708,7 @@ __global__ __launch_bounds__(256) void k_ffn_block_h(const FfnHArgs a) {
     {
         f32x4 acc2[2][4];
         acc_zero(acc2);
-        gemm_packed<2, 4>(Hh, ldhh, a.w2, a.FF >> 5, wave * 4, 16, a.FF >> 5, acc2);
+        gemm_packed<2, 4>(Hh, ldhh, a.w2, a.FF >> 5, wave * 4, 16, a.FF >> 5, acc2, ring2);
         acc_store_lds<2, 4>(acc2, Cs, ld, wave * 64, bias2, SEEME_ACT_NONE);
     }
     __syncthreads();
