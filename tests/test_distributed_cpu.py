@@ -35,7 +35,9 @@ def _worker(rank, ws, port, q):
     n = D.allreduce_gradients(params)
     # 3) metric sums
     s = D.reduce_sums(torch.tensor([1.0 + rank, 10.0, 1.0], dtype=torch.float64))
-    q.put((rank, all_ranges, n, lin.weight.grad.clone(), extra.grad.clone(), s))
+    # plain lists, not tensors: a tensor travels as a file descriptor served by THIS process, and the parent may come for
+    # it after this process has exited (FileNotFoundError on the resource-sharer socket, seen once in ~20 runs)
+    q.put((rank, all_ranges, n, lin.weight.grad.tolist(), extra.grad.tolist(), s.tolist()))
     dist.destroy_process_group()
 
 
@@ -57,9 +59,9 @@ def test_world2_gloo():
     # mean of per-rank grads: d/dW sum(Wx+b) = x summed over rows -> 3*(rank+1); mean over ranks = 4.5
     for r in res:
         assert r[2] == 8 * 4 + 4 + 5
-        assert torch.allclose(r[3], torch.full((4, 8), 4.5))
-        assert torch.equal(r[4], torch.zeros(5))
-        assert torch.allclose(r[5], torch.tensor([3.0, 20.0, 2.0], dtype=torch.float64))
+        assert torch.allclose(torch.tensor(r[3]), torch.full((4, 8), 4.5))
+        assert torch.equal(torch.tensor(r[4]), torch.zeros(5))
+        assert torch.allclose(torch.tensor(r[5], dtype=torch.float64), torch.tensor([3.0, 20.0, 2.0], dtype=torch.float64))
 
 
 def test_single_process_is_identity():
