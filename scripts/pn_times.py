@@ -35,6 +35,6 @@ if hasattr(lib, "seeme_debug_pn_times"):
     names = ["land tile in LDS + barrier", "fc_0 gemm", "barrier", "hidden write + barrier", "fc_1 gemm", "shortcut gemm",
              "issue next tile", "epilogue from registers", "barrier"]
     d = np.diff(t)
-    print("total cycles", t[-1] - t[0])
+    print("total cycles", t[-1] - t[0], " epilogue split: rows+stores", buf[10] - buf[7], "max reduce + smax", buf[8] - buf[10])
     for i, x in enumerate(d):
         print(f"  {names[i]}: {x:.0f}")

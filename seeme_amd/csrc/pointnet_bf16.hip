@@ -29,7 +29,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 typedef unsigned int pn_u32x4 __attribute__((ext_vector_type(4)));
 typedef short pn_s16x4 __attribute__((ext_vector_type(4)));
+#ifndef PN_PF
 #define PN_PF 4                                            // weight fragments in flight: PN_PF k-blocks x 4 n-tiles per wave
+#endif
 
 // One packed matrix as a buffer resource + this wave's n-tile offset (everything scalar; the lane part is one VGPR).
 template <int KS>
@@ -391,6 +393,7 @@ __global__ __launch_bounds__(256 * MH, 2) void k_pn_block(const PnBlockArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);             // one row tile at a time: the ring and the prefetched tile stay in registers
             }
+            PN_DBG(10);
             // column max over the wave's 64 points: the 16 lanes of a DPP row hold 16 points of the same 16 features.
             // Reduce-scatter (15 exchanges instead of 16 x 4): each step a lane keeps half of its values and takes the
             // partner's copy of that half; lane r ends with feature r of the group.  Partners: r^8 (row_ror:8),
