@@ -9,7 +9,11 @@ One "step" = one pass of the path over one batch of synthetic input, per GPU:
 All inputs are resident in HBM before the timed region.  Weights are random-init by the seeded
 recipe (no checkpoint exists offline); data is synthetic N(0,1) of the named shape.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+N>1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or -- when WORLD_SIZE
+is not set -- this process starts the N ranks itself as child processes BEFORE anything touches the GPU and relays
+rank 0's line.  `--mode train` times the stage-2 training step instead (BASELINE configs[2] at N=1: scene + interactee,
+B=64/GPU, 20 000-point scenes; configs[3] at N>1: config_mld_gimo, scene only), with the gradient all-reduce over RCCL.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` (dominant kernel,
 timed with events on its own stream) and `cpu_baseline` (the PyTorch-CPU oracle on the host cores, N=1 only).
@@ -148,6 +152,141 @@ def cpu_baseline(B, budget_s=12.0):
                       + ", ".join(f"{k}t {v:.2f}" for k, v in trials.items()) + ")"}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process, which has not
+    touched the GPU (no HIP call, no torch.cuda.is_available()) and never will; rank 0 prints the JSON line on the
+    inherited stdout.  Returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            for p in procs:
+                if p.poll() not in (None, 0):              # one rank died: the others would wait in a collective for ever
+                    for q in procs:
+                        if q.poll() is None:
+                            q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    return rc
+
+
+PN_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak ~2.5 PFLOP/s
+
+
+def pointnet_flops(B, P):
+    """(executed, reference-graph) FLOPs of one PointNet encode.  Executed: fc_pos_0 3->512, block_0 = fc_0 512->256 +
+    fc_1 256->256 (+ the folded 3->256 shortcut), blocks 1-3 = fc_0 / shortcut on the 256 per-point features (the pooled
+    half is a per-scene vector) + fc_1.  Reference graph: SURVEY section 6, 52.49 GF per 20 000 points."""
+    per_point = 2 * 3 * 512 + (2 * 512 * 256 + 2 * 256 * 256 + 2 * 4 * 256) + 3 * (3 * 2 * 256 * 256)
+    return float(B) * P * per_point, float(B) * P * 52.49e9 / 20000.0
+
+
+def train_mode(args, dev, rank, world, backend, dist_on):
+    """One step = stage-2 training step on one batch per GPU: frozen PointNet + frozen VAE encodes (HIP), denoiser
+    forward + hand-written backward (HIP), one in-place all-reduce of the flat gradient buffer, one-launch AdamW."""
+    from seeme_amd.config import parse_config
+    from seeme_amd.mld import MLD, SyntheticEgoDataModule
+    from seeme_amd.smpl import SMPL
+    from seeme_amd.weights_recipe import load_recipe_
+    from seeme_amd import distributed as D
+    which = args.train_config or ("scene" if world == 1 else "gimo")
+    cfgfile = {"scene": "config_mld_scene.yaml", "gimo": "config_mld_gimo.yaml", "egobody": "config_mld_egobody.yaml"}[which]
+    cfg = parse_config(os.path.join(REPO, "configs", cfgfile))
+    cfg.TRAIN.FROZEN_VAE_PRECISION = args.vae
+    cfg.TRAIN.SCENE_PRECISION = "bf16"
+    nfeats = 69 if cfg.DATASET_NAME == "gimo" else 75
+    B, P = args.batch, args.points
+    dm = SyntheticEgoDataModule(nfeats=nfeats, T=T_FRAMES, n_points=P, seed=1234, device=dev)
+    model = MLD(cfg, dm, smpl_model=SMPL.synthetic(1234))
+    load_recipe_(model.vae), load_recipe_(model.denoiser)
+    with_scene = "scene" in cfg.model.condition
+    if with_scene:
+        load_recipe_(model.proscene.scene_enc)
+    model = model.to(dev).train()
+    D.broadcast_parameters(model)
+    model.configure_optimizers()
+    batches = [dm.batch(B, idx=2 * rank + i, with_scene=with_scene) for i in range(2)]     # resident in HBM
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    pn_ev = []
+    if args.graph:
+        replay = model.capture_training_step(batches[0])
+        step = lambda i, e=None: replay(batches[i % 2])
+    else:
+        def step(i, e=None):
+            if e is not None and with_scene:
+                model.proscene.scene_enc.timing_events = (e[4], e[5])
+            loss = model.training_step(batches[i % 2], i)
+            model.optimizer_step(loss, events=e[:4] if e is not None else None)
+            return loss
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    evs = [[ev() for _ in range(6)] for _ in range(args.steps)]
+    if dist_on:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i, evs[i])
+    torch.cuda.synchronize()
+    if dist_on:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(loss.detach()).all()
+    if with_scene:
+        model.proscene.scene_enc.timing_events = None
+    res = {
+        "metric": "stage-2 training seqs/sec (T=196, B=%d/GPU%s)" % (B, ", %d-point scenes" % P if with_scene else ""),
+        "value": round(world * B * args.steps / dt, 2), "unit": "seqs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": f"f32 (denoiser forward/backward, AdamW; frozen encoders: bf16 PointNet MFMA operands, {args.vae} VAE operands)",
+        "data": "synthetic",
+        "config": {"workload": f"{cfgfile}: stage-2 training step, condition {list(cfg.model.condition)}, B={B}/GPU, T=196, "
+                               f"nfeats={nfeats}" + (f", {P}-point scenes" if with_scene else "") + ", random-init recipe weights",
+                   "batch_per_gpu": B, "global_batch": B * world, "seq_len": T_FRAMES,
+                   "parallelism": f"dp{world} (one in-place all-reduce of the flat fp32 gradient buffer per step)"
+                                  + (", hipGraph replay" if args.graph else "")},
+        "rccl_ranks": torch.distributed.get_world_size() if dist_on else 1,
+        "collective_backend": (backend if dist_on else None),
+        "grad_bucket_bytes": (int(model.grad_bucket().flat.numel() * 4) if model.grad_bucket() is not None else None),
+    }
+    if not args.graph:
+        ph = lambda a, b: round(float(np.mean([e[a].elapsed_time(e[b]) for e in evs])), 4)
+        res["phases_ms"] = {"backward": ph(0, 1), "allreduce": ph(1, 2), "adamw": ph(2, 3)}
+        if with_scene:
+            pn_ms = float(np.mean([e[4].elapsed_time(e[5]) for e in evs]))
+            exe, refg = pointnet_flops(B, P)
+            ach = exe / (pn_ms * 1e-3) / 1e12
+            res["phases_ms"]["pointnet"] = round(pn_ms, 4)
+            res["roofline"] = {"bound": "mfma", "kernel": "seeme_pointnet_encode_bf16 (4 x k_pn_block + pooled-vector maps), "
+                               "the dominant part of the step", "achieved": round(ach, 2), "peak": PN_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(ach / PN_PEAK_TFLOPS, 4), "traffic": None,
+                               "ms_per_launch": round(pn_ms, 4), "executed_flops_per_launch": exe,
+                               "reference_graph_flops_per_launch": refg,
+                               "work_equivalent_tflops": round(refg / (pn_ms * 1e-3) / 1e12, 2)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,14 +302,24 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="capture each stream's pass (47 launches) as one hipGraph and time replays: the serving configuration, "
                          "host cost per pass ~15 us instead of ~2.5 ms of Python")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train"],
+                    help="sample = the headline metric (BASELINE configs[1]); train = the stage-2 training step (configs[2] / configs[3])")
+    ap.add_argument("--train-config", default=None, choices=["scene", "gimo", "egobody"],
+                    help="--mode train: scene = scene + interactee (configs[2], default at 1 GPU), gimo = config_mld_gimo scene-only "
+                         "(configs[3], default at N > 1), egobody = interactee only")
+    ap.add_argument("--points", type=int, default=20000, help="--mode train: points per scene cloud")
     ap.add_argument("--scheduler", default="ddim", choices=["ddim", "ddpm"], help="ddpm = 1000-step ancestral sampling (BASELINE configs[4])")
     args = ap.parse_args()
+    if args.mode == "train" and args.batch == 32 and "--batch" not in sys.argv:
+        args.batch = 64                                     # BASELINE configs[2] / [3]: 64 sequences per GPU
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:    # no launcher: start the ranks ourselves, GPU untouched here
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+        raise SystemExit(f"bench.py needs an MI355X (no CPU fallback on the product path) [rank {rank} of {world}]")
     # rehearsal on a one-GPU box: SEEME_BENCH_BACKEND=gloo SEEME_BENCH_DEVICE=0 puts every rank on one card
     backend = os.environ.get("SEEME_BENCH_BACKEND", "nccl")
     if "SEEME_BENCH_DEVICE" in os.environ:
@@ -185,6 +334,14 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if args.mode == "train":
+        res = train_mode(args, dev, rank, world, backend, dist_on)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if dist_on:
+            dist.destroy_process_group()
+        return
 
     B = args.batch
     S = max(1, args.streams)
@@ -280,8 +437,10 @@ def main():
             "dtype": "f32" if (args.weights == "fp32" and args.vae == "fp32") else
                      f"f32 accumulate ({args.weights} denoiser weights, {args.vae} VAE MFMA operands)",
             "data": "synthetic",
-            "config": {"workload": f"config_mld_egobody interactee-only: VAE encode -> 50-step DDIM -> VAE decode, "
-                                   f"B={B}/GPU, T=196, nfeats=132, random-init recipe weights",
+            "rccl_ranks": dist.get_world_size() if dist_on else 1,
+            "collective_backend": (backend if dist_on else None),
+            "config": {"workload": f"config_mld_egobody interactee-only: VAE encode -> " + (f"{n_infer}-step DDIM" if args.scheduler == "ddim" else f"{n_infer}-step DDPM (ancestral)")
+                                   + f" -> VAE decode, B={B}/GPU, T=196, nfeats=132, random-init recipe weights",
                        "batch_per_gpu": B, "seq_len": T_FRAMES, "ddim_steps": n_infer,
                        "parallelism": f"dp{world} (independent shards, no collective on the data path)"
                                       + (f", {S} batches in flight per GPU" if S > 1 else "") + (", hipGraph replay" if args.graph else "")},

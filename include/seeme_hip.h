@@ -310,6 +310,14 @@ int seeme_adamw_step(const void* chunks, int n_chunks, void* const* params, cons
                      void* const* exp_avg_sq, double lr, double beta1, double beta2, double eps, double weight_decay,
                      double step, void* stream);
 
+/* The same update with the step count and the learning rate read from device memory (step_lr = {step, lr}, the caller
+ * increments step_lr[0] on the stream before the launch): nothing in the launch depends on host state, so a captured
+ * hipGraph of the whole training step (MLD.capture_training_step) advances correctly from replay to replay.  Replaces the
+ * same optimiser step as seeme_adamw_step. */
+int seeme_adamw_step_dev(const void* chunks, int n_chunks, void* const* params, const void* const* grads, void* const* exp_avg,
+                         void* const* exp_avg_sq, const float* step_lr, double beta1, double beta2, double eps,
+                         double weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

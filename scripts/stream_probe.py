@@ -4,7 +4,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from seeme_amd import _lib as L
-lib = L.lib()
+from probes import probe_lib
+lib = probe_lib.lib()
 f = lib.seeme_debug_stream
 f.restype = C.c_int
 f.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -19,13 +20,13 @@ for blocks in (1, 32, 256):
     for mode, ring in ((0, 0), (1, 8), (1, 16)):
         out = torch.zeros(blocks * 512, device=dev)
         for _ in range(2):
-            L.check(f(src.data_ptr(), nbytes, reps, mode, ring, blocks, out.data_ptr(), L.current_stream()))
+            probe_lib.check(f(src.data_ptr(), nbytes, reps, mode, ring, blocks, out.data_ptr(), L.current_stream()))
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         n = 3
         for _ in range(n):
-            L.check(f(src.data_ptr(), nbytes, reps, mode, ring, blocks, out.data_ptr(), L.current_stream()))
+            probe_lib.check(f(src.data_ptr(), nbytes, reps, mode, ring, blocks, out.data_ptr(), L.current_stream()))
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n

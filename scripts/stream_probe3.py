@@ -4,7 +4,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from seeme_amd import _lib as L
-lib = L.lib()
+from probes import probe_lib
+lib = probe_lib.lib()
 f = lib.seeme_debug_stream_rr
 f.restype = C.c_int
 f.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -17,12 +18,12 @@ for blocks in (32,):
     for ring in (2, 3, 4, 6):
         for per_gemv, epi in ((0, 0), (2, 0), (2, 8), (2, 24), (4, 8), (4, 24), (8, 8), (8, 24)):
             for _ in range(2):
-                L.check(f(src.data_ptr(), nbytes, nchunks, ring, per_gemv, epi, blocks, out.data_ptr(), L.current_stream()))
+                probe_lib.check(f(src.data_ptr(), nbytes, nchunks, ring, per_gemv, epi, blocks, out.data_ptr(), L.current_stream()))
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                L.check(f(src.data_ptr(), nbytes, nchunks, ring, per_gemv, epi, blocks, out.data_ptr(), L.current_stream()))
+                probe_lib.check(f(src.data_ptr(), nbytes, nchunks, ring, per_gemv, epi, blocks, out.data_ptr(), L.current_stream()))
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 3
@@ -38,12 +39,12 @@ for c in (2, 4, 8):
     ngemv = nchunks // c
     for epi in (0, 8, 24):
         for _ in range(2):
-            L.check(g(src.data_ptr(), nbytes, ngemv, c, 0, epi, blocks, out.data_ptr(), L.current_stream()))
+            probe_lib.check(g(src.data_ptr(), nbytes, ngemv, c, 0, epi, blocks, out.data_ptr(), L.current_stream()))
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(3):
-            L.check(g(src.data_ptr(), nbytes, ngemv, c, 0, epi, blocks, out.data_ptr(), L.current_stream()))
+            probe_lib.check(g(src.data_ptr(), nbytes, ngemv, c, 0, epi, blocks, out.data_ptr(), L.current_stream()))
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3

@@ -123,6 +123,7 @@ _SIGNATURES = {
     "seeme_den_wgrad": (C.c_int, [fp, C.c_int, C.c_int, fp, C.c_int, fp, fp]),
     "seeme_adamw_step": (C.c_int, [fp, C.c_int, fp, fp, fp, fp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_double, fp]),
+    "seeme_adamw_step_dev": (C.c_int, [fp, C.c_int, fp, fp, fp, fp, fp, C.c_double, C.c_double, C.c_double, C.c_double, fp]),
     "seeme_geometry": (C.c_int, [C.c_int, fp, fp, C.c_int, fp]),
     "seeme_renorm": (C.c_int, [fp, fp, fp, fp, C.c_long, C.c_int, fp]),
     "seeme_pointnet_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),

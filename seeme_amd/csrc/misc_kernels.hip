@@ -159,10 +159,20 @@ extern "C" int seeme_pointnet_encode(const SeemePointnetWeights* w, const float*
 // 27 launches and ~0.5 ms on the 204 trainable tensors (8.0 M elements) of stage 2, a pure HBM stream of 224 MB.
 // chunks[c] = {tensor id, element offset, element count}; p / m / v / g = per-tensor base pointers.
 struct AdamWChunk { int tensor, count; long long offset; };
+// DEV: the step count and the learning rate come from device memory (dev = {step, lr}), so that the launch can sit in a
+// captured hipGraph and still advance from replay to replay; the scalar factors are then formed here, in double.
+template <bool DEV>
 __global__ __launch_bounds__(256) void k_adamw(const AdamWChunk* __restrict__ chunks, float* const* __restrict__ ps,
                                                const float* const* __restrict__ gs, float* const* __restrict__ ms,
                                                float* const* __restrict__ vs, float decay, float one_minus_beta1, float beta2,
-                                               float one_minus_beta2, float step_size, float sqrt_bias_c2, float eps) {
+                                               float one_minus_beta2, float step_size, float sqrt_bias_c2, float eps,
+                                               const float* __restrict__ dev, double beta1d, double beta2d, double wd) {
+    if (DEV) {
+        const double step = (double)dev[0], lr = (double)dev[1];
+        decay = (float)(1.0 - lr * wd);
+        step_size = (float)(lr / (1.0 - pow(beta1d, step)));
+        sqrt_bias_c2 = (float)sqrt(1.0 - pow(beta2d, step));
+    }
     const AdamWChunk ch = chunks[blockIdx.x];
     float* __restrict__ p = ps[ch.tensor] + ch.offset;
     const float* __restrict__ g = gs[ch.tensor] + ch.offset;
@@ -196,10 +206,21 @@ extern "C" int seeme_adamw_step(const void* chunks, int n_chunks, void* const* p
     if (n_chunks <= 0) return 0;
     if (!(step >= 1.0)) return seeme_fail("adamw: step must be >= 1");
     const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
-    hipLaunchKernelGGL(k_adamw, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamWChunk*)chunks,
+    hipLaunchKernelGGL(k_adamw<false>, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamWChunk*)chunks,
                        (float* const*)params, (const float* const*)grads, (float* const*)exp_avg, (float* const*)exp_avg_sq,
                        (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                       (float)(lr / bc1), (float)sqrt(bc2), (float)eps);
+                       (float)(lr / bc1), (float)sqrt(bc2), (float)eps, (const float*)nullptr, 0.0, 0.0, 0.0);
     return seeme_check_launch("k_adamw");
 }
 
+extern "C" int seeme_adamw_step_dev(const void* chunks, int n_chunks, void* const* params, const void* const* grads,
+                                    void* const* exp_avg, void* const* exp_avg_sq, const float* step_lr, double beta1, double beta2,
+                                    double eps, double weight_decay, void* stream) {
+    if (n_chunks <= 0) return 0;
+    if (!step_lr) return seeme_fail("adamw: step_lr is NULL");
+    hipLaunchKernelGGL(k_adamw<true>, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamWChunk*)chunks,
+                       (float* const*)params, (const float* const*)grads, (float* const*)exp_avg, (float* const*)exp_avg_sq,
+                       0.f, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 0.f, 0.f, (float)eps, step_lr, beta1, beta2,
+                       weight_decay);
+    return seeme_check_launch("k_adamw<dev>");
+}

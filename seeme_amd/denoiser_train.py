@@ -155,14 +155,11 @@ class TrainPack:
                 vec(self.index[(l, i, "nb")], o + 256, 256)
         vec(1, fin, 256)                           # encoder.norm.weight / bias
         vec(2, fin + 256, 256)
-        self.gflat = torch.zeros(off, device=dev, dtype=torch.float32)
-        self.vec_region = self.gflat[vec0:off]
+        self.gflat_numel, self._vec0, self._spans = off, vec0, spans
         self.gather_idx = torch.tensor(gather, device=dev, dtype=torch.int64)
-        for pos, o, shape in spans:
-            n = 1
-            for d in shape:
-                n *= d
-            self.grad_views[pos] = self.gflat[o:o + n].view(*shape)
+        self.dx0_span = (fin + 512, fin + 768)
+        self.bound, self._attached = False, False
+        self._attach(torch.zeros(off, device=dev, dtype=torch.float32), torch.zeros_like(self.params[0]))
         # tiles of seeme_den_wgrad: {int x_col, y_col, ldo, nn, kk, pad; int64 out_off} per 32 x 256 block of every matrix
         tiles = []
         for name, ls, moff, Nn, K in self.mat_blocks:
@@ -175,15 +172,47 @@ class TrainPack:
                                       o & 0xFFFFFFFF if o < 2 ** 31 else o - 2 ** 32, o >> 32])
         self._wgrad_tiles = torch.tensor(tiles, dtype=torch.int32).to(dev)
         self._n_wgrad_tiles = len(tiles)
-        self.dpe = torch.zeros_like(self.params[0])                     # query_pos.pe: only row 0 is on the path
-        self.grad_views[0] = self.dpe
-        self.dx0_span = (fin + 512, fin + 768)
+
+    def _attach(self, storage: torch.Tensor, dpe: torch.Tensor):
+        """Point the gradient views at `storage` (gflat_numel floats) and `dpe` (query_pos.pe: only row 0 is on the path)."""
+        self.gflat = storage
+        self.vec_region = storage[self._vec0:self.gflat_numel]
+        for pos, o, shape in self._spans:
+            n = 1
+            for d in shape:
+                n *= d
+            self.grad_views[pos] = storage[o:o + n].view(*shape)
+        self.dpe = dpe
+        self.grad_views[0] = dpe
+
+    def bind(self, storage: torch.Tensor, dpe: torch.Tensor):
+        """Write the chain's gradients straight into a caller-owned block (distributed.GradBucket): the parameters'
+        ``.grad`` ARE these views, so reduce_into_grads overwrites in place and never touches ``.grad``."""
+        assert storage.numel() == self.gflat_numel and storage.is_contiguous()
+        self._attach(storage, dpe if dpe is not None else torch.zeros_like(self.params[0]))
+        self.bound = True
 
     def reduce_into_grads(self, gout: torch.Tensor):
         """dW = sum_b dy_b x_b^T (one batched GEMM per matrix kind), bias / LayerNorm gradients = column sums; then
         hand the views to ``.grad`` (accumulating where a gradient already exists, e.g. the in_proj rows the tables share)."""
         B = gout.shape[0]
         DBL = self.lay["DB_LAYER"]
+        if self.bound and gout.is_cuda:
+            colsum = gout.sum(0)
+            L.check(L.lib().seeme_den_wgrad(gout.data_ptr(), gout.shape[1], B, self._wgrad_tiles.data_ptr(), self._n_wgrad_tiles,
+                                            self.gflat.data_ptr(), L.current_stream()), "seeme_den_wgrad")
+            self.vec_region.copy_(colsum.index_select(0, self.gather_idx))
+            self.dpe[0, 0].copy_(colsum[self.dx0_span[0]:self.dx0_span[1]])
+            if self._attached:                                 # GradBucket.prepare() made .grad these very views
+                self._attached = False
+                return
+            for p, v in zip(self.params, self.grad_views):     # a backward outside the bucket's step: same contract as below
+                if p.requires_grad:
+                    if p.grad is None:
+                        p.grad = v
+                    elif p.grad.data_ptr() != v.data_ptr():
+                        p.grad.add_(v)
+            return
         live = any(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.grad_views))
         flat = torch.empty_like(self.gflat) if live else self.gflat   # a previous backward's gradients are still in use
         colsum = gout.sum(0)

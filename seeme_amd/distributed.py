@@ -49,10 +49,77 @@ def shard_range(n: int, rank: int = None, ws: int = None) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class GradBucket:
+    """Every trainable gradient of a model in ONE flat fp32 buffer whose views are the parameters' ``.grad``
+    (what DDP calls ``gradient_as_bucket_view``): autograd accumulates into the views in place, the hand-written
+    denoiser backward writes its region directly (``TrainPack.bind``), and the data-parallel exchange is a single
+    ``all_reduce`` of the buffer -- no concatenation before it, no copy back after it (C1: 32 MB for stage 2).
+
+    Layout: [the chain's gradient block of ``pack`` (denoiser_train.TrainPack), if any | every other trainable
+    parameter in ``parameters`` order].  ``prepare()`` before each backward re-attaches the views and zeroes the part
+    autograd accumulates into; gradient accumulation over several backwards is not what this object is for."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], pack=None):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("GradBucket: no trainable parameters")
+        dev = self.params[0].device
+        self.pack = pack
+        in_pack = {}
+        n_pack = 0
+        if pack is not None:
+            n_pack = pack.gflat_numel
+            in_pack = {id(p): i for i, p in enumerate(pack.params)}
+        off = n_pack
+        spans = []
+        for p in self.params:
+            i = in_pack.get(id(p))
+            if i is not None and i != 0:          # position 0 is query_pos.pe: a whole [500,1,256] tensor, kept outside
+                continue
+            spans.append((p, off))
+            off += p.numel()
+        self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.n_pack = n_pack
+        self.views = {}
+        for p, o in spans:
+            self.views[id(p)] = self.flat[o:o + p.numel()].view_as(p)
+        if pack is not None:
+            pack.bind(self.flat[:n_pack], self.views.get(id(pack.params[0])))
+            for i, p in enumerate(pack.params):
+                if i != 0 and p.requires_grad:
+                    self.views[id(p)] = pack.grad_views[i]
+        self._pack_key = None if pack is None else id(pack)
+
+    def matches(self, pack) -> bool:
+        return self._pack_key == (None if pack is None else id(pack))
+
+    def prepare(self):
+        """Before backward: ``.grad`` = the views; zero what autograd adds into (the chain block is overwritten)."""
+        self.flat[self.n_pack:].zero_()
+        for p in self.params:
+            v = self.views[id(p)]
+            if p.grad is not v:
+                p.grad = v
+        if self.pack is not None:
+            self.pack._attached = True
+
+    def allreduce(self, average: bool = True) -> int:
+        rank, ws = world()
+        if ws > 1:
+            if average and dist.get_backend() == "nccl":
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                if average:
+                    self.flat.div_(ws)
+        return int(self.flat.numel())
+
+
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = True) -> int:
     """Mean all-reduce of every .grad as one flat bucket; parameters without a gradient (e.g. mem_pos.pe,
     which trans_enc never touches) contribute zeros so that all ranks agree on the layout.
-    Returns the number of elements reduced."""
+    Returns the number of elements reduced.  (Generic form for gradients that live in separate tensors: it has to
+    gather them and scatter the result.  The training loop keeps them in a GradBucket instead and reduces in place.)"""
     params = [p for p in params if p.requires_grad]
     if not params:
         return 0

@@ -7,13 +7,19 @@ without Lightning: ``training_step / validation_step / test_step / allsplit_step
 What runs where
   * VAE encode/decode, the whole reverse-diffusion loop, the denoiser forward, PointNet, SMPL, rotation
     helpers and renorm run in libseeme_hip.so (HIP kernels for gfx950).
-  * Stage-2 *training* needs d(loss)/d(denoiser weights): this round the backward pass is PyTorch-ROCm
-    autograd over ``denoiser_autograd.denoiser_forward_torch`` (same parameters, checked against the HIP
-    forward in tests); the frozen parts of the step (VAE encodes, PointNet) are HIP.  Stage-1 (VAE)
-    training is not accelerated yet: ``train_vae_forward`` produces the forward quantities only.
+  * Stage-2 *training*: the frozen encoders and the denoiser forward + hand-written backward
+    (``denoiser_train.py``: ``k_den_sample`` with saves, ``k_den_bwd``, ``seeme_den_wgrad``) are HIP; the table builders
+    around the chain are batched torch ops carried by autograd; every gradient lives in one flat buffer
+    (``distributed.GradBucket``) that is all-reduced in place and consumed by the one-launch AdamW.  More than one
+    attention head falls back to the autograd twin (``denoiser_autograd.py``).
+  * Stage-1 (VAE) training runs through differentiable twins of the VAE and the SMPL joint regressor
+    (``vae_autograd.py``) on PyTorch-ROCm autograd; evaluation of that stage is HIP.
   * Only the live flows are implemented; the reference's dead code (``forward`` calling the undefined
     ``feats2joints``, t2m_eval, the ``save_for_edo`` debug dump -- SURVEY.md App. D) is not reproduced:
     ``forward``/``sample`` = what ``ego_eval`` really does (condition -> reverse diffusion -> decode).
+  * Deliberate, documented deviations from the reference: none by default.  ``TEST.SAMPLE_MEAN``
+    (condition on the posterior mean instead of a sample) and ``TEST.CFG_SCENE_ORDER: fixed`` (classifier-free guidance
+    with the unconditional scene token in the unconditional half) are opt-in.
 """
 from __future__ import annotations
 
@@ -66,7 +72,9 @@ class MLDLosses:
             jr, jp = rs["joints_ref"], rs["joints_rst"]
             if self.predict_transl:
                 jr, jp, pg, pp = self.align_root(jr, jp)
-                total = total + self._acc("recons_transl", sl1(pp, pg), L.LAMBDA_ROOT)
+                # weight: the reference's elif chain tests split('_')[0] == 'recons' before 'transl' (losses/mld.py:80-97),
+                # so recons_transl is weighted by LAMBDA_REC and its LAMBDA_ROOT branch is unreachable
+                total = total + self._acc("recons_transl", sl1(pp, pg), L.LAMBDA_REC)
             total = total + self._acc("recons_feature", sl1(rs["m_rst"], rs["m_ref"]), L.LAMBDA_REC)
             total = total + self._acc("recons_joints", sl1(jp, jr), L.get("LAMBDA_JOINT", 1.0))
             if L.LAMBDA_KL != 0.0:
@@ -181,13 +189,16 @@ class EgoMetrics:
 
 
 class SyntheticEgoDataModule:
-    """Batches with the EgoBody/GIMO tuple layout (mld/data/humanml/data/dataset.py:1754-1794): motion
-    [B,T,2,72], transl [B,2,T,3], beta [B,2,T,10], utils [B,T,6], scene [B,P,3], length [B,1]; mean/std
+    """Batches with the EgoBody/GIMO tuple layout (mld/data/humanml/data/dataset.py:1754-1794, 2479-2509): motion
+    [B,T,2,72 | 66], transl [B,2,T,3], beta [B,2,T,10], utils [B,T,6], scene [B,P,3], length [B,1]; mean/std
     for ``renorm`` (mld/data/EgoBody.py:151-157).  Datasets are licence-gated, so this is what tests and
     benchmarks run on."""
 
-    def __init__(self, nfeats=75, T=196, n_points=2048, seed=1234, device="cpu"):
+    def __init__(self, nfeats=75, T=196, n_points=2048, seed=1234, device="cpu", pose_dim=None):
         self.nfeats, self.T, self.n_points = nfeats, T, n_points
+        # per-person pose width of `motion`: EgoBody 72 (24 joints, axis-angle), GIMO 66 (root + 21 joints); the VAE sees
+        # pose + 3 translation values = nfeats when TRAIN.ABLATION.PREDICT_TRANSL (mld.py:121-123)
+        self.pose_dim = int(pose_dim) if pose_dim is not None else nfeats - 3
         g = torch.Generator().manual_seed(seed)
         self.mean = (0.1 * torch.randn(1, nfeats + 16, generator=g)).to(device)
         self.std = (0.5 + torch.rand(1, nfeats + 16, generator=g)).to(device)
@@ -201,7 +212,7 @@ class SyntheticEgoDataModule:
     def batch(self, B, idx=0, with_scene=False, lengths=None, pose_estimation=False):
         g = torch.Generator().manual_seed(self.seed * 7919 + idx)
         T = self.T
-        motion = 0.5 * torch.randn(B, T, 2, 72, generator=g)
+        motion = 0.5 * torch.randn(B, T, 2, self.pose_dim, generator=g)
         transl = torch.randn(B, 2, T, 3, generator=g)
         beta = 0.5 * torch.randn(B, 2, 1, 10, generator=g).expand(B, 2, T, 10).contiguous()
         utils_ = torch.zeros(B, T, 6)
@@ -214,7 +225,7 @@ class SyntheticEgoDataModule:
         if with_scene and not pose_estimation:
             out.append([])          # img_path / dict_images slot
         if pose_estimation:         # interactee ground truth: motion [B,T,1,72], transl [B,1,T,3], beta [B,T,1,10] (mld.py:1119-1131)
-            noise = 0.05 * torch.randn(B, T, 72, generator=g)
+            noise = 0.05 * torch.randn(B, T, self.pose_dim, generator=g)
             out += [(motion[:, :, 1] + noise).unsqueeze(2).to(dev), transl[:, 1:2].clone().to(dev), beta[:, 1].unsqueeze(2).to(dev)]
         return tuple(out)
 
@@ -249,6 +260,13 @@ class MLD(nn.Module):
         self.predict_transl = cfg.TRAIN.ABLATION.PREDICT_TRANSL
         self.data_type = cfg.DATA_TYPE
         self.see_future = cfg.TEST.get("SEE_FUTURE", False)
+        self.pred_global_orient = cfg.TEST.get("GLOBAL_ORIENT_PRED", True)           # mld.py:111
+        # reference behaviour by default: the interactee condition is a SAMPLE of the posterior (mld.py:1280) and the CFG
+        # scene pair is concatenated [cond, uncond] (mld.py:1144-1158) although _diffusion_reverse reads [uncond, cond]
+        self.sample_mean = bool(cfg.TEST.get("SAMPLE_MEAN", False))
+        self.cfg_scene_order = str(cfg.TEST.get("CFG_SCENE_ORDER", "reference"))
+        if self.cfg_scene_order not in ("reference", "fixed"):
+            raise ValueError("TEST.CFG_SCENE_ORDER must be 'reference' or 'fixed'")
         self.hip_backward = cfg.TRAIN.get("HIP_BACKWARD", True)   # hand-written backward of the denoiser chain (one head)
         self.pose_estimation_task = cfg.TEST.get("POSE_ESTIMATION_TASK", False)      # mld.py:116
         if self.name_dataset == "egobody":                               # mld.py:122-125
@@ -300,6 +318,9 @@ class MLD(nn.Module):
 
     # ------------------------------------------------------------------ optimiser (mld.py:292-299, base.py:157-158)
     def configure_optimizers(self, capturable: bool = False):
+        if self.optimizer is not None and capturable and not self.optimizer.param_groups[0].get("capturable", False):
+            raise RuntimeError("configure_optimizers(capturable=True): an optimiser built with capturable=False exists "
+                               "(capture_training_step does not need a capturable torch AdamW: it uses seeme_adamw_step_dev)")
         if self.optimizer is None:
             params = [p for p in self.parameters() if p.requires_grad]
             self.optimizer = torch.optim.AdamW(params, lr=self.cfg.TRAIN.OPTIM.LR, capturable=capturable)
@@ -324,10 +345,11 @@ class MLD(nn.Module):
         return [p for p in self.parameters() if p.requires_grad]
 
     # ------------------------------------------------------------------ condition assembly
-    def _scene_token(self, scene, cfg_mask_train=False):
+    def _scene_token(self, scene, cfg_mask_train=False, mask=None):
         scene = scene.float()
         if cfg_mask_train and self.do_classifier_free_guidance:           # mld.py:917-919
-            mask = torch.rand_like(scene) < self.guidance_uncodp
+            if mask is None:
+                mask = torch.rand_like(scene) < self.guidance_uncodp
             scene = torch.where(mask, torch.zeros_like(scene), scene)
         s512 = self.proscene.encode_scene(scene)                          # HIP PointNet
         # output_scene = ReLU + Linear(512,256) (trainable, mld.py:257-261): torch op so that autograd sees it
@@ -337,7 +359,23 @@ class MLD(nn.Module):
         f = feats_ref[:, :, idx, :]
         if self.predict_transl:
             f = torch.cat([f, transl[:, idx, :, :]], dim=-1)
-        return f[..., : self.nfeats].contiguous() if f.shape[-1] > self.nfeats else f.contiguous()
+        if f.shape[-1] != self.vae.nfeats:
+            raise ValueError(f"motion features are {f.shape[-1]} wide (pose {feats_ref.shape[-1]}"
+                             f"{' + 3 translation' if self.predict_transl else ''}) but the VAE was built with nfeats "
+                             f"{self.vae.nfeats} (model.nfeats)")
+        return f.contiguous()
+
+    def _sample_latent(self, feats, lengths, eps=None, mean=False):
+        """vae.encode(...)[0] of the reference (a posterior sample, mld_vae.py:186-193) with the noise injectable:
+        eps [1,B,256] replaces the draw; mean=True returns mu.  Returns (z [1,B,256], Normal)."""
+        dist = self.vae.encode_dist(feats, lengths)
+        mu, std = dist[0:1], dist[1:2].exp().pow(0.5)
+        normal = torch.distributions.Normal(mu, std, validate_args=False)
+        if mean:
+            return mu, normal
+        if eps is None:
+            eps = torch.empty_like(mu).normal_()
+        return mu + eps.to(mu) * std, normal
 
     # ------------------------------------------------------------------ reverse diffusion (mld.py:432-511)
     def _diffusion_reverse(self, encoder_hidden_states, lengths=None, latents=None, step_noise=None):
@@ -383,10 +421,15 @@ class MLD(nn.Module):
         return n_set
 
     # ------------------------------------------------------------------ stage-2 training forward (mld.py:887-1017)
-    def train_diffusion_forward(self, batch, noise=None, timesteps=None):
+    def train_diffusion_forward(self, batch, noise=None, timesteps=None, eps=None, masks=None):
+        """Injection points for parity tests (not in the reference), in the order the reference draws: masks =
+        (scene mask, interactee mask) -- the boolean results of ``rand_like(x) < guidance_uncondp`` (:917-919, :966-968),
+        eps = (target rsample noise, condition rsample noise) [1,B,256] each, then `noise` and `timesteps` (:591-601)."""
+        m_scene, m_int = masks if masks is not None else (None, None)
+        e_z, e_c = eps if eps is not None else (None, None)
         if "scene" in self.condition:
             feats_ref, transl, beta, utils_, scene, length = batch[:6]
-            scene = self._scene_token(scene, cfg_mask_train=True)
+            scene = self._scene_token(scene, cfg_mask_train=True, mask=m_scene)
         else:
             feats_ref, transl, beta, utils_, length = batch[:5]
             scene = None
@@ -396,24 +439,25 @@ class MLD(nn.Module):
             idx = 0 if self.estimate == "wearer" else 1
             f_tgt = self._wearer_features(feats_ref, transl, idx)
             z_cond = None
+            B = f_tgt.shape[0]
+            shape = (1, B, self.vae.latent_dim)
+            draw = lambda e: torch.empty(shape, device=f_tgt.device, dtype=torch.float32).normal_() if e is None else e.to(f_tgt)
             if "interactee" in self.condition:
                 # target and interactee go through the frozen VAE as ONE batch of 2B sequences (the encode is a chain of
                 # ~20 latency-bound launches); the three random draws keep the order of the two separate encodes:
                 # rsample noise of the target, the CFG input mask, rsample noise of the condition (mld.py:944-984)
-                B = f_tgt.shape[0]
-                shape = (1, B, self.vae.latent_dim)
-                eps_z = torch.empty(shape, device=f_tgt.device, dtype=torch.float32).normal_()
+                eps_z = draw(e_z)
                 f_int = self._wearer_features(feats_ref, transl, 1)
                 if self.do_classifier_free_guidance:                       # mld.py:966-981
-                    mask = torch.rand_like(f_int) < self.guidance_uncodp
+                    mask = (torch.rand_like(f_int) < self.guidance_uncodp) if m_int is None else m_int
                     f_int = torch.where(mask, torch.zeros_like(f_int), f_int)
-                eps_c = torch.empty(shape, device=f_tgt.device, dtype=torch.float32).normal_()
+                eps_c = draw(e_c)
                 dist = self.vae.encode_dist(torch.cat([f_tgt, f_int], dim=0), lengths + lengths)      # [2, 2B, 256]
                 mu, std = dist[0:1], dist[1:2].exp().pow(0.5)              # mld_vae.py:186-190
                 z = mu[:, :B] + eps_z * std[:, :B]                         # Normal(mu, std).rsample(), :192
                 z_cond = mu[:, B:] + eps_c * std[:, B:]
             else:
-                z, _ = self.vae.encode(f_tgt, None, lengths)
+                z, _ = self._sample_latent(f_tgt, lengths, e_z)
         if scene is not None and z_cond is not None:
             cond_emb = torch.cat([z_cond, scene], dim=0)                    # :991-993
         elif scene is not None:
@@ -424,47 +468,58 @@ class MLD(nn.Module):
             raise ValueError("no condition: MldDenoiser needs at least one condition token")
         return {**self._diffusion_process(z, cond_emb, lengths, noise=noise, timesteps=timesteps)}
 
-    # ------------------------------------------------------------------ stage-1 forward (mld.py:633-885), no grad
-    def train_vae_forward(self, batch):
+    # ------------------------------------------------------------------ stage-1 forward (mld.py:633-885)
+    def train_vae_forward(self, batch, eps=None):
+        """encode -> rsample -> decode -> renorm -> SMPL joints of reference and reconstruction.  m_ref / m_rst are the
+        RENORMED features, as in the reference (mld.py:757,778,871-878).  GIMO keeps the first 21 joints and poses the
+        reconstruction with the reference's global orientation (:826-828,852-859).  eps [1,B,256]: injected rsample noise."""
         feats_ref, transl, beta = batch[0].float(), batch[1].float(), batch[2].float()
         lengths = [feats_ref.shape[1]] * feats_ref.shape[0]
         idx = 0 if self.estimate == "wearer" else 1
         f_ref = self._wearer_features(feats_ref, transl, idx)
+        gimo = self.name_dataset == "gimo" and self.data_type == "angle"
+        nj = 21 if gimo else 24
+        m_ref = self.renorm(f_ref)
+        ref_orient = m_ref[:, :, :3] if gimo else None
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.vae.parameters()):
-            # stage-1 training: differentiable twins of the VAE and the SMPL joint regressor (PyTorch-ROCm autograd;
-            # a hand-written backward for this stage is not built)
+            # stage-1 training: differentiable twins of the VAE and the SMPL joint regressor (PyTorch-ROCm autograd)
             from .vae_autograd import vae_encode_torch, vae_decode_torch
             mu, std = vae_encode_torch(self.vae, f_ref, lengths)
             dist_m = torch.distributions.Normal(mu, std, validate_args=False)
-            z = dist_m.rsample()
-            feats_rst = vae_decode_torch(self.vae, z, lengths)
+            z = dist_m.rsample() if eps is None else mu + eps.to(mu) * std
+            m_rst = self.renorm(vae_decode_torch(self.vae, z, lengths))
             with torch.no_grad():
-                joints_ref = self._feats_to_joints(self.renorm(f_ref), beta[:, idx])
-            joints_rst = self._feats_to_joints_torch(self.renorm(feats_rst), beta[:, idx])
+                joints_ref = self._feats_to_joints(m_ref, beta[:, idx])[:, :, :nj]
+            joints_rst = self._feats_to_joints_torch(m_rst, beta[:, idx], orient=ref_orient)[:, :, :nj]
         else:
-            z, dist_m = self.vae.encode(f_ref, None, lengths)
-            feats_rst = self.vae.decode(z, lengths)
-            joints_ref = self._feats_to_joints(self.renorm(f_ref), beta[:, idx])
-            joints_rst = self._feats_to_joints(self.renorm(feats_rst), beta[:, idx])
-        dist_ref = torch.distributions.Normal(torch.zeros_like(dist_m.loc), torch.ones_like(dist_m.scale))
-        return {"m_ref": f_ref, "m_rst": feats_rst, "joints_ref": joints_ref, "joints_rst": joints_rst,
+            z, dist_m = self._sample_latent(f_ref, lengths, eps)
+            m_rst = self.renorm(self.vae.decode(z, lengths))
+            joints_ref = self._feats_to_joints(m_ref, beta[:, idx])[:, :, :nj]
+            joints_rst = self._feats_to_joints(m_rst, beta[:, idx], orient=ref_orient)[:, :, :nj]
+        if self.is_vae:                                                    # mld.py:683-691
+            dist_ref = torch.distributions.Normal(torch.zeros_like(dist_m.loc), torch.ones_like(dist_m.scale))
+        else:
+            dist_ref = dist_m
+        return {"m_ref": m_ref, "m_rst": m_rst, "joints_ref": joints_ref, "joints_rst": joints_rst,
                 "dist_m": dist_m, "dist_ref": dist_ref, "lat_m": z.permute(1, 0, 2)}
 
     # ------------------------------------------------------------------ features -> SMPL joints
-    def _feats_to_joints(self, feats, betas, want_vertices=False):
+    def _feats_to_joints(self, feats, betas, want_vertices=False, orient=None):
         """feats [B,T,F] (renormed).  'angle': [global_orient 3 | body_pose 21..23 joints | transl 3];
-        'rot6d': 24 x 6.  Returns joints [B,T,24,3] (and vertices)."""
+        'rot6d': 24 x 6 (the reference builds that body model in float64, mld.py:161-163).  orient [B,T,3]: global
+        orientation to pose with instead of the features' own.  Returns joints [B,T,24,3] (and vertices)."""
         B, T, F = feats.shape
         if self.data_type == "rot6d":                                      # mld.py:1410-1449
-            R = G.rot6d_to_rotmat(feats[..., :144].reshape(-1, 6)).reshape(B * T, 24, 3, 3)
-            out = self.smpl_model(betas=betas.reshape(-1, 10).float(), body_pose=R[:, 1:], global_orient=R[:, 0:1],
+            R = G.rot6d_to_rotmat(feats[..., :144].reshape(-1, 6).contiguous()).reshape(B * T, 24, 3, 3)
+            zb = torch.zeros(B * T, 10, device=feats.device, dtype=torch.float32)     # create_beta=False: betas are not passed
+            out = self.smpl_model(betas=zb, body_pose=R[:, 1:], global_orient=R[:, 0:1],
                                   pose2rot=False, return_verts=want_vertices, transl=None)
         else:
             nb = 69 if self.name_dataset == "egobody" else 63
             body = feats[:, :, 3:3 + nb].reshape(-1, nb).float()
             if nb < 69:                                                    # GIMO pads 21 -> 23 joints (mld.py:807-813)
                 body = torch.cat([body, torch.zeros(body.shape[0], 69 - nb, device=body.device)], dim=1)
-            go = feats[:, :, :3].reshape(-1, 3).float()
+            go = (feats[:, :, :3] if orient is None else orient).reshape(-1, 3).float()
             tr = feats[:, :, -3:].reshape(-1, 3).float().contiguous() if self.predict_transl else None
             out = self.smpl_model(betas=betas.reshape(-1, 10).float(), body_pose=body.contiguous(),
                                   global_orient=go.contiguous(), transl=tr, pose2rot=True, return_verts=want_vertices)
@@ -473,14 +528,17 @@ class MLD(nn.Module):
             return joints, out.vertices.reshape(B, T, -1, 3)
         return joints
 
-    def _feats_to_joints_torch(self, feats, betas):
+    def _feats_to_joints_torch(self, feats, betas, orient=None):
         """Differentiable version of _feats_to_joints for stage-1 training ('angle' data: axis-angle pose)."""
         from .vae_autograd import smpl_joints_torch
         if self.data_type != "angle":
             raise NotImplementedError("stage-1 training twin: DATA_TYPE 'angle'")
         B, T, _ = feats.shape
         nb = 69 if self.name_dataset == "egobody" else 63
-        pose = feats[:, :, :3 + nb].reshape(B * T, 3 + nb)
+        pose = feats[:, :, :3 + nb]
+        if orient is not None:
+            pose = torch.cat([orient.to(pose), pose[:, :, 3:]], dim=-1)
+        pose = pose.reshape(B * T, 3 + nb)
         if nb < 69:                                                        # GIMO pads 21 -> 23 joints (mld.py:807-813)
             pose = torch.cat([pose, torch.zeros(B * T, 69 - nb, device=pose.device, dtype=pose.dtype)], dim=1)
         tr = feats[:, :, -3:].reshape(B * T, 3) if self.predict_transl else None
@@ -488,47 +546,60 @@ class MLD(nn.Module):
 
     # ------------------------------------------------------------------ evaluation (mld.py:1076-1905, live part)
     @torch.no_grad()
-    def ego_eval(self, batch, latents=None, want_vertices=False):
+    def ego_eval(self, batch, latents=None, want_vertices=False, cond_noise=None, step_noise=None):
+        """Injection points for parity tests (not in the reference): latents [B,1,256] initial noise; cond_noise = eps
+        [1,B,256] of the condition sample (stage 'vae': of the target's sample), or a pair (eps_cond, eps_uncond) with
+        classifier-free guidance; step_noise for DDPM."""
         int_gt = None
         if self.pose_estimation_task:       # batch ends with the interactee's ground truth (mld.py:1119-1131)
             batch, int_gt = tuple(batch[:-3]), tuple(t.float() for t in batch[-3:])
+        eps_c, eps_u = cond_noise if isinstance(cond_noise, (tuple, list)) else (cond_noise, None)
         if "scene" in self.condition:
             feats_ref, transl, beta, utils_, scene, length = batch[:6]
-            scene_tok = self._scene_token(scene)
-            if self.do_classifier_free_guidance:                           # zero-scene uncond branch (:1144-1158)
-                scene_tok = torch.cat([self._scene_token(torch.zeros_like(scene)), scene_tok], dim=1)
+            scene_tok = None
+            if self.stage != "vae":
+                scene_tok = self._scene_token(scene)
+                if self.do_classifier_free_guidance:                       # zero-scene branch (:1144-1158)
+                    unc = self._scene_token(torch.zeros_like(scene))
+                    # the reference concatenates [scene, scene_uncond] while _diffusion_reverse takes the FIRST half as
+                    # unconditional (:489): reproduced by default, TEST.CFG_SCENE_ORDER 'fixed' puts uncond first
+                    scene_tok = torch.cat([scene_tok, unc] if self.cfg_scene_order == "reference" else [unc, scene_tok], dim=1)
         else:
             feats_ref, transl, beta, utils_, length = batch[:5]
             scene_tok = None
         feats_ref, transl, beta = feats_ref.float(), transl.float(), beta.float()
         lengths = length.long().reshape(-1).tolist()
+        idx_ref = 0 if self.estimate == "wearer" else 1
         start = time.time()
-        text_emb = None
-        if "interactee" in self.condition:                                 # :1271-1295
-            f_int = self._wearer_features(feats_ref, transl, 1)
-            text_emb = self.vae.encode_dist(f_int, lengths)[0:1]
-            # NOTE the reference takes vae.encode(...)[0], the *sampled* latent; `sample_mean` keeps eval deterministic
-            if not getattr(self, "sample_mean", True):
-                text_emb, _ = self.vae.encode(f_int, None, lengths)
-            if self.do_classifier_free_guidance:
-                unc = self.vae.encode_dist(torch.zeros_like(f_int), lengths)[0:1]
-                text_emb = torch.cat([unc, text_emb], dim=1)
-        toks = [t for t in (text_emb, scene_tok) if t is not None]
-        if not toks:
-            raise ValueError("no condition tokens")
-        cond_emb = torch.cat(toks, dim=0)                                   # [N, B or 2B, 256]
-        z = self._diffusion_reverse(cond_emb.permute(1, 0, 2), lengths, latents=latents)
+        if self.stage in ("diffusion", "vae_diffusion"):
+            text_emb = None
+            if "interactee" in self.condition:                             # :1271-1295
+                f_int = self._wearer_features(feats_ref, transl, 1)
+                text_emb, _ = self._sample_latent(f_int, lengths, eps_c, mean=self.sample_mean)
+                if self.do_classifier_free_guidance:
+                    unc, _ = self._sample_latent(torch.zeros_like(f_int), lengths, eps_u, mean=self.sample_mean)
+                    text_emb = torch.cat([unc, text_emb], dim=1)
+            toks = [t for t in (text_emb, scene_tok) if t is not None]
+            if not toks:
+                raise ValueError("no condition tokens")
+            cond_emb = torch.cat(toks, dim=0)                               # [N, B or 2B, 256]
+            z = self._diffusion_reverse(cond_emb.permute(1, 0, 2), lengths, latents=latents, step_noise=step_noise)
+        elif self.stage == "vae":                                          # :1328-1352: reconstruction of the target itself
+            z, _ = self._sample_latent(self._wearer_features(feats_ref, transl, idx_ref), lengths, eps_c, mean=self.sample_mean)
+        else:
+            raise ValueError(f"Not support this stage {self.stage}!")
         if self.see_future:
             lengths = [int(i // 2) for i in lengths]
         feats_rst = self.vae.decode(z, lengths)
         self.times.append(time.time() - start)                              # mld.py:1367-1368
-        idx_ref = 0 if self.estimate == "wearer" else 1
         min_len = min(feats_ref.shape[1], feats_rst.shape[1])
         f_ref = self._wearer_features(feats_ref[:, :min_len], transl[:, :, :min_len], idx_ref)
         f_ref, f_rst = self.renorm(f_ref), self.renorm(feats_rst[:, :min_len].contiguous())
         b_ref = beta[:, idx_ref, :min_len]
+        # egobody: TEST.GLOBAL_ORIENT_PRED False poses the prediction with the reference orientation (:1497-1501)
+        o_rst = f_ref[:, :, :3] if (self.data_type == "angle" and self.name_dataset == "egobody" and not self.pred_global_orient) else None
         out_ref = self._feats_to_joints(f_ref, b_ref, want_vertices)
-        out_rst = self._feats_to_joints(f_rst, b_ref, want_vertices)
+        out_rst = self._feats_to_joints(f_rst, b_ref, want_vertices, orient=o_rst)
         joints_ref, joints_rst = (out_ref[0], out_rst[0]) if want_vertices else (out_ref, out_rst)
         f_int_r = self.renorm(self._wearer_features(feats_ref[:, :min_len], transl[:, :, :min_len], 1))
         joints_int = self._feats_to_joints(f_int_r, beta[:, 1, :min_len])
@@ -538,10 +609,13 @@ class MLD(nn.Module):
             f_gt = g_motion[:, :min_len, 0]
             if self.predict_transl:
                 f_gt = torch.cat([f_gt, g_transl[:, 0, :min_len]], dim=-1)
-            joints_int_gt = self._feats_to_joints(self.renorm(f_gt[..., : self.nfeats].contiguous()), beta[:, 1, :min_len])
-        quat = (lambda f: G.aa_to_quat(f[:, :, :3].reshape(-1, 3).contiguous())) if self.data_type == "angle" else (lambda f: None)
+            joints_int_gt = self._feats_to_joints(self.renorm(f_gt.contiguous()), beta[:, 1, :min_len])
+        if self.data_type == "angle":
+            quat = lambda f, o=None: G.aa_to_quat((f[:, :, :3] if o is None else o).reshape(-1, 3).contiguous())
+        else:
+            quat = lambda f, o=None: None
         rs = {"m_ref": f_ref, "m_rst": f_rst, "joints_ref": joints_ref, "joints_rst": joints_rst,
-              "orientation_quat_rst": quat(f_rst), "orientation_quat_ref": quat(f_ref),
+              "orientation_quat_rst": quat(f_rst, o_rst), "orientation_quat_ref": quat(f_ref),
               "root_interactee": joints_int[:, :, 0], "joints_interactee": joints_int,
               "orientation_quat_int": quat(f_int_r), "joints_interactee_gt": joints_int_gt, "lengths": lengths,
               "list_names": {}, "lat_t": z}
@@ -585,34 +659,43 @@ class MLD(nn.Module):
 
     def capture_training_step(self, batch, warmup: int = 3):
         """One stage-2 training step (frozen HIP encoders, denoiser forward + backward, AdamW) captured as ONE
-        hipGraph on static input buffers -- the launch-bound chain of ~10^3 small kernels replays without host work.
-        Returns replay(new_batch=None) -> loss tensor (static).  World size 1 only captures the optimiser too;
-        with data parallelism the gradient all-reduce and the optimiser step stay eager after the replay."""
+        hipGraph on static input buffers -- the launch-bound chain of small kernels replays without host work.
+        Returns replay(new_batch=None) -> loss tensor (static).  The AdamW update in the graph is the one-launch
+        ``seeme_adamw_step_dev`` on the existing optimiser's state (step count and learning rate live on the device, so
+        replays advance them and an LR-scheduler edit reaches the graph); with data parallelism the graph ends after
+        backward and the gradient all-reduce + optimiser step stay eager after the replay."""
         from . import distributed as D
         world = D.world()[1]
-        self.configure_optimizers(capturable=True)
+        self.configure_optimizers()
+        fused = getattr(self, "_fused_adamw", None)
+        if fused is None:
+            raise NotImplementedError("capture_training_step needs the one-launch AdamW (TRAIN.FUSED_ADAMW, ROCm parameters): "
+                                      "torch.optim.AdamW built with capturable=False cannot be stepped inside a capture")
+        if self.stage != "diffusion":
+            raise NotImplementedError("capture_training_step: stage 'diffusion'")
         static = [b.clone() if torch.is_tensor(b) else b for b in batch]
         losses = self.losses["train"]
 
         def step():
             loss = losses.update(self.train_diffusion_forward(static), accumulate=False)
-            loss.backward()
+            self.backward(loss)
             if world == 1:
-                self.optimizer.step()
+                fused.step(device_step=True)
             return loss
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self.optimizer.zero_grad(set_to_none=True)
+            # real steps: the first discovers the parameters on the path, the next ones create the gradient bucket and the
+            # optimiser's pointer tables -- all of which must exist before the capture
+            for _ in range(max(3 if self.grad_bucket() is None else 1, warmup)):
                 step()
                 if world > 1:
-                    D.allreduce_gradients(self.trainable_parameters())
-                    self.optimizer.step()
+                    b = self.grad_bucket()
+                    D.allreduce_gradients(self._used_params) if b is None else b.allreduce()
+                    self.optimizer_update()
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        self.optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(graph):
             static_loss = step()
 
@@ -621,20 +704,66 @@ class MLD(nn.Module):
                 for dst, src in zip(static, new_batch):
                     if torch.is_tensor(dst):
                         dst.copy_(src)
+            if world == 1:
+                fused.sync_lr()
             graph.replay()
             if world > 1:
-                D.allreduce_gradients(self.trainable_parameters())
-                self.optimizer.step()
+                self.grad_bucket().allreduce()
+                self.optimizer_update()
+            else:
+                fused.note_replay()
             return static_loss
 
         return replay
 
-    def optimizer_step(self, loss, world=None):
+    def grad_bucket(self):
+        """The flat gradient buffer (distributed.GradBucket) of the parameters that RECEIVE gradients -- known after the
+        first backward, which runs on separate tensors (a parameter off the path, e.g. denoiser.mem_pos.pe, keeps
+        ``.grad`` None for ever, so AdamW never decays it, as in the reference) -- laid out around the HIP backward's own
+        gradient block when stage 2 trains through it; rebuilt when that block is re-created.  None before that first step."""
+        from . import distributed as D
+        used = getattr(self, "_used_params", None)
+        if used is None:
+            return None
+        pack = getattr(self.denoiser, "_train_pack", None) if self.stage == "diffusion" and self.hip_backward else None
+        b = getattr(self, "_bucket", None)
+        if b is None or not b.matches(pack):
+            b = D.GradBucket(used, pack)
+            self._bucket = b
+        return b
+
+    def backward(self, loss):
+        """loss.backward() into the flat bucket; the very first call discovers which parameters are on the path.
+        Returns the bucket (None on the discovery step)."""
+        b = self.grad_bucket()
+        if b is None:
+            for p in self.trainable_parameters():
+                p.grad = None
+            loss.backward()
+            self._used_params = [p for p in self.trainable_parameters() if p.grad is not None]
+            return None
+        b.prepare()
+        loss.backward()
+        return b
+
+    def optimizer_step(self, loss, events=None):
         """backward -> (data-parallel) gradient all-reduce -> AdamW step; what Lightning + DDP do around
-        training_step in the reference (train.py:127-149)."""
+        training_step in the reference (train.py:127-149).  Every gradient lives in one flat buffer, so the exchange is
+        ONE all_reduce of it in place.  `events`: optional 4 torch.cuda.Event (start, after backward, after all-reduce,
+        after AdamW) recorded on the current stream."""
         from . import distributed as D
         self.configure_optimizers()
-        self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
-        D.allreduce_gradients(self.trainable_parameters())
+        if events is not None:
+            events[0].record()
+        bucket = self.backward(loss)
+        if events is not None:
+            events[1].record()
+        if bucket is None:
+            D.allreduce_gradients(self._used_params)
+        else:
+            bucket.allreduce()
+        if events is not None:
+            events[2].record()
         self.optimizer_update()
+        if events is not None:
+            events[3].record()

@@ -26,6 +26,7 @@ class FusedAdamWStep:
         self.opt = optimizer
         self._key = None
         self._shared = {}
+        self._dev_scalars, self._dev_lr = {}, {}
 
     def _tables(self, params: List[torch.nn.Parameter]):
         """Static device tables (chunks, parameter / moment pointers); rebuilt when the tensors behind them change."""
@@ -50,9 +51,15 @@ class FusedAdamWStep:
         self._key = key
 
     def _grad_pointers(self, grads, dev):
-        """Per-step table of gradient base pointers (autograd re-allocates most of them every step): pinned host
-        buffers, two in rotation, copied asynchronously -- a pageable copy would stall the host on the whole backward."""
+        """Table of gradient base pointers.  With the gradients in a GradBucket the addresses never change and the table
+        is uploaded once; otherwise autograd re-allocates most of them every step: pinned host buffers, two in rotation,
+        copied asynchronously -- a pageable copy would stall the host on the whole backward."""
         n = len(grads)
+        key = tuple(g.data_ptr() for g in grads)
+        if getattr(self, "_gp_key", None) == key:
+            return self._gp_dev
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FusedAdamWStep: gradient addresses changed inside a graph capture (run warm-up steps first)")
         if getattr(self, "_gp_host", None) is None or self._gp_host[0].numel() != n:
             self._gp_host = [torch.empty(n, dtype=torch.int64).pin_memory() for _ in range(2)]
             self._gp_ev = [None, None]
@@ -62,15 +69,46 @@ class FusedAdamWStep:
         self._gp_i ^= 1
         if self._gp_ev[i] is not None:
             self._gp_ev[i].synchronize()                  # the copy that last read this host buffer has run
-        self._gp_host[i].copy_(torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64))
+        self._gp_host[i].copy_(torch.tensor(key, dtype=torch.int64))
         self._gp_dev.copy_(self._gp_host[i], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._gp_ev[i] = ev
+        self._gp_key = key
         return self._gp_dev
 
+    def _device_scalars(self, group, shared, dev):
+        """{step, lr} on the device for the graph-capturable launch; the host copies stay authoritative for checkpoints."""
+        sc = self._dev_scalars.get(id(group))
+        if sc is None:
+            sc = torch.tensor([float(shared), float(group["lr"])], dtype=torch.float32, device=dev)
+            self._dev_scalars[id(group)] = sc
+            self._dev_lr[id(group)] = float(group["lr"])
+        elif self._dev_lr[id(group)] != float(group["lr"]) and not torch.cuda.is_current_stream_capturing():
+            sc[1].fill_(float(group["lr"]))               # the LR scheduler edited the group
+            self._dev_lr[id(group)] = float(group["lr"])
+        return sc
+
+    def sync_lr(self):
+        """Push a learning rate the LR scheduler edited to the device-side scalars (before replaying a captured step)."""
+        for group in self.opt.param_groups:
+            k = id(group)
+            if k in self._dev_scalars and self._dev_lr[k] != float(group["lr"]):
+                self._dev_scalars[k][1].fill_(float(group["lr"]))
+                self._dev_lr[k] = float(group["lr"])
+
+    def note_replay(self):
+        """A captured step was replayed: advance the host-side step counts (the device-side count advanced in the graph)."""
+        for group in self.opt.param_groups:
+            shared = self._shared.get(id(group))
+            if shared is not None:
+                shared.add_(1.0)
+
     @torch.no_grad()
-    def step(self):
+    def step(self, device_step: bool = False):
+        """device_step: step count and learning rate are read from device memory (seeme_adamw_step_dev), which makes the
+        launch capturable in a hipGraph; inside a capture the host-side step count is left to note_replay()."""
+        capturing = torch.cuda.is_current_stream_capturing()
         for group in self.opt.param_groups:
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
@@ -95,15 +133,27 @@ class FusedAdamWStep:
                 self._shared[id(group)] = shared
                 for p in params:
                     self.opt.state[p]["step"] = shared
-            step = float(shared) + 1.0
-            shared.fill_(step)
+                self._dev_scalars.pop(id(group), None)
             self._tables(params)
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in params]
             gp = self._grad_pointers(grads, params[0].device)
             b1, b2 = group["betas"]
-            L.check(L.lib().seeme_adamw_step(self._chunks.data_ptr(), self._n_chunks, self._p.data_ptr(), gp.data_ptr(),
-                                             self._m.data_ptr(), self._v.data_ptr(), float(group["lr"]), float(b1), float(b2),
-                                             float(group["eps"]), float(group["weight_decay"]), float(step),
-                                             L.current_stream()), "seeme_adamw_step")
+            if device_step:
+                sc = self._device_scalars(group, shared, params[0].device)
+                sc[0:1].add_(1.0)
+                if not capturing:
+                    shared.add_(1.0)
+                L.check(L.lib().seeme_adamw_step_dev(self._chunks.data_ptr(), self._n_chunks, self._p.data_ptr(), gp.data_ptr(),
+                                                     self._m.data_ptr(), self._v.data_ptr(), sc.data_ptr(), float(b1), float(b2),
+                                                     float(group["eps"]), float(group["weight_decay"]), L.current_stream()),
+                        "seeme_adamw_step_dev")
+            else:
+                step = float(shared) + 1.0
+                shared.fill_(step)
+                self._dev_scalars.pop(id(group), None)    # the device-side count (if any) is stale now
+                L.check(L.lib().seeme_adamw_step(self._chunks.data_ptr(), self._n_chunks, self._p.data_ptr(), gp.data_ptr(),
+                                                 self._m.data_ptr(), self._v.data_ptr(), float(group["lr"]), float(b1), float(b2),
+                                                 float(group["eps"]), float(group["weight_decay"]), float(step),
+                                                 L.current_stream()), "seeme_adamw_step")
             self._keep = (grads, gp)                      # alive until the next step (the launch is asynchronous)
         self.opt._opt_called = True                       # what the LR scheduler's wrapper of optimizer.step() records

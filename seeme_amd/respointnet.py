@@ -99,6 +99,9 @@ class ResnetPointnet(nn.Module):
         if self._ws is None or self._ws.numel() < need or self._ws.device != p.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=p.device)
         w = self._weights()
+        ev = getattr(self, "timing_events", None)       # (start, end) torch.cuda.Event pair: bench.py brackets the encode
+        if ev is not None:
+            ev[0].record()
         if bf16:
             wb = self._wcache[3]
             L.check(L.lib().seeme_pointnet_encode_bf16(C.byref(w), C.byref(wb), p.data_ptr(), B, P, out.data_ptr(),
@@ -107,4 +110,6 @@ class ResnetPointnet(nn.Module):
         else:
             L.check(L.lib().seeme_pointnet_encode(C.byref(w), p.data_ptr(), B, P, out.data_ptr(), self._ws.data_ptr(),
                                                    self._ws.numel(), L.current_stream()), "seeme_pointnet_encode")
+        if ev is not None:
+            ev[1].record()
         return out

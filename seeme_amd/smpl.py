@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import pickle
 from types import SimpleNamespace
 from typing import Optional
 
@@ -42,6 +43,43 @@ def synthetic_model_arrays(seed: int = 1234, V: int = 6890):
                 parents=np.asarray(SMPL_PARENTS, np.int64), faces=np.zeros((13776, 3), np.int64))
 
 
+class _ChumpyStub:
+    """Placeholder for ``chumpy.ch.Ch`` objects of the original SMPL pickles: keeps the state dict, exposes the array."""
+
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else {"x": state})
+
+    def array(self):
+        return np.asarray(self.__dict__.get("x", self.__dict__.get("r")))
+
+
+class _RestrictedUnpickler(pickle.Unpickler):
+    """An SMPL model file is arrays, a sparse matrix and strings.  Only the reconstructors of those are allowed
+    (numpy arrays / dtypes / scalars, scipy.sparse matrices, chumpy arrays as inert stubs); any other global in the file
+    -- i.e. anything that could run code on load -- is refused."""
+
+    _ALLOWED = {
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+        ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+        ("numpy", "ndarray"), ("numpy", "dtype"), ("collections", "OrderedDict"),
+        ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+        ("_codecs", "encode"),                    # how protocol-2 pickles carry the bytes of an array (pure string -> bytes)
+        ("copy_reg", "_reconstructor"), ("copyreg", "_reconstructor"), ("__builtin__", "object"), ("builtins", "object"),
+        ("scipy.sparse.csc", "csc_matrix"), ("scipy.sparse._csc", "csc_matrix"),
+        ("scipy.sparse.csr", "csr_matrix"), ("scipy.sparse._csr", "csr_matrix"),
+        ("scipy.sparse.coo", "coo_matrix"), ("scipy.sparse._coo", "coo_matrix"),
+    }
+
+    def find_class(self, module, name):
+        if module.startswith("chumpy"):
+            return _ChumpyStub
+        if (module, name) in self._ALLOWED:
+            import importlib
+            return getattr(importlib.import_module(module), name)
+        raise pickle.UnpicklingError(f"SMPL model file refers to {module}.{name}: only numpy / scipy.sparse / chumpy "
+                                     "array reconstructors are accepted (convert the file to .npz otherwise)")
+
+
 def _load_model_file(path: str):
     if os.path.isdir(path):
         for cand in ("SMPL_NEUTRAL.npz", "SMPL_NEUTRAL.pkl"):
@@ -52,9 +90,9 @@ def _load_model_file(path: str):
         with np.load(path, allow_pickle=False) as z:
             d = {k: z[k] for k in z.files}
     else:  # user-supplied SMPL pickle (licence-gated download, prepare/download_smpl_model.sh)
-        import pickle
         with open(path, "rb") as f:
-            d = pickle.load(f, encoding="latin1")
+            d = _RestrictedUnpickler(f, encoding="latin1").load()
+        d = {k: (v.array() if isinstance(v, _ChumpyStub) else v) for k, v in d.items()}
     out = {}
     out["v_template"] = np.asarray(d["v_template"], np.float32)
     out["shapedirs"] = np.asarray(d["shapedirs"], np.float32)[:, :, :10]

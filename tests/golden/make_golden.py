@@ -8,8 +8,10 @@ numpy PCG64; outputs are whatever the reference modules compute on CPU in fp32, 
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden.py
 
 What is pinned by the reference:  MldVae.encode/decode, MldDenoiser.forward, Timesteps,
-ResnetPointnet, geometry2 helpers.  The 50-step loop fixture drives the reference denoiser with
-the build's restated DDIM step (diffusers is absent: scheduler parity unpinned).
+ResnetPointnet, geometry2 helpers, MLDLosses (losses.npz) and -- through the OpenAI-style
+GaussianDiffusion the tree vendors under EgoHMR/ -- the DDIM / DDPM update formulas for the alpha-bar
+sequence MLD's scheduler configuration visits (schedulers_egohmr.npz).  The 50-step loop fixture drives
+the reference denoiser with the build's restated DDIM step (diffusers itself is absent).
 """
 import os
 import sys
@@ -161,6 +163,105 @@ def misc_case():
          points=pts, pointnet=pn(torch.from_numpy(pts)).numpy())
 
 
+def losses_case():
+    """The reference's own MLDLosses (mld/models/losses/mld.py:10-188) on fixed tensors with NON-UNIT lambdas.  Its base
+    class torchmetrics.Metric is not installed; the six-line stand-in below only provides ``add_state`` (a named
+    attribute), every weight, loss function and the whole ``update`` arithmetic are the reference's."""
+    tm = types.ModuleType("torchmetrics")
+
+    class Metric(torch.nn.Module):
+        def __init__(self, **kw):
+            super().__init__()
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            setattr(self, name, default.clone() if torch.is_tensor(default) else default)
+
+    tm.Metric = Metric
+    sys.modules.setdefault("torchmetrics", tm)
+    from mld.models.losses.mld import MLDLosses
+    lam = dict(LAMBDA_LATENT=1e-5, LAMBDA_KL=3e-3, LAMBDA_REC=0.7, LAMBDA_JOINT=1.9, LAMBDA_GEN=1.0, LAMBDA_CROSS=1.0,
+               LAMBDA_CYCLE=0.0, LAMBDA_PRIOR=0.0, LAMBDA_ROOT=0.31, DIST_SYNC_ON_STEP=False)
+    g = rng("losses")
+    B, T, F = 3, 7, 75
+    arr = lambda *shape, scale=1.0: (g.standard_normal(shape) * scale).astype(np.float32)
+    rs = dict(m_ref=arr(B, T, F), m_rst=arr(B, T, F, scale=1.7), joints_ref=arr(B, T, 24, 3), joints_rst=arr(B, T, 24, 3, scale=2.0),
+              mu=arr(1, B, 256, scale=0.5), std=np.exp(arr(1, B, 256, scale=0.3)).astype(np.float32),
+              noise=arr(B, 1, 256), noise_pred=arr(B, 1, 256, scale=1.2), latent=arr(B, 1, 256), pred=arr(B, 1, 256))
+    out = {k: v for k, v in rs.items()}
+    out["lambdas"] = np.array([lam[k] for k in ("LAMBDA_KL", "LAMBDA_REC", "LAMBDA_JOINT", "LAMBDA_ROOT")], np.float64)
+    for stage, eps_pred in (("vae", True), ("diffusion", True), ("diffusion", False)):
+        cfg = types.SimpleNamespace(
+            LOSS=types.SimpleNamespace(**lam),
+            TRAIN=types.SimpleNamespace(STAGE=stage, ABLATION=types.SimpleNamespace(VAE_TYPE="actor", PREDICT_EPSILON=eps_pred,
+                                                                                 PREDICT_TRANSL=True)))
+        L = MLDLosses(vae=True, mode="ego", cfg=cfg)
+        t = {k: torch.from_numpy(v.copy()) for k, v in rs.items()}
+        t["dist_m"] = torch.distributions.Normal(t["mu"], t["std"])
+        t["dist_ref"] = torch.distributions.Normal(torch.zeros_like(t["mu"]), torch.ones_like(t["std"]))
+        total = L.update(t)
+        tag = stage + ("" if eps_pred else "_x")
+        out[f"{tag}_total"] = np.float64(total.item())
+        for name in L.losses:
+            out[f"{tag}_{name}"] = np.float64(float(getattr(L, name)))
+        if stage == "vae":       # align_root replaced the dict entries (losses/mld.py:119-121)
+            out["aligned_joints_ref"], out["aligned_joints_rst"] = t["joints_ref"].numpy(), t["joints_rst"].numpy()
+    save("losses.npz", **out)
+
+
+def scheduler_case():
+    """Scheduler arithmetic the reference tree DOES hold: EgoHMR/diffusion/gaussian_diffusion.py (OpenAI formulation):
+    ``ddim_sample`` (:511-557), ``p_sample`` (:298-338) and ``q_sample`` (:189-207).  ``diffusers`` itself is absent
+    (SURVEY section 8c), so this is the one executable cross-check of the DDIM / DDPM update formulas: a
+    GaussianDiffusion is built on the alpha-bar sequence the MLD scheduler configuration visits
+    (configs/modules/scheduler.yaml:1-14: scaled_linear 0.00085..0.012, 50 steps, steps_offset 1, set_alpha_to_one
+    False => alpha-bar_prev of the last step is alpha-bar[0]), and its outputs for given (x_t, eps, noise) are stored."""
+    sys.path.insert(0, os.path.join(REF, "EgoHMR"))
+    from diffusion.gaussian_diffusion import GaussianDiffusion
+    acp = np.cumprod(1.0 - (np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2))
+    ts = (np.arange(50) * 20 + 1).astype(np.int64)                    # ascending DDIM timesteps 1, 21, ..., 981
+    abar = np.concatenate([[acp[0]], acp[ts]])                         # index 0 = the "previous" of t = 1
+    betas = 1.0 - abar / np.concatenate([[1.0], abar[:-1]])
+    gd = GaussianDiffusion(betas=betas)
+    assert np.allclose(gd.alphas_cumprod, abar)
+    g = rng("sched")
+    B = 4
+    x = g.standard_normal((B, 1, 256)).astype(np.float32)
+    eps = g.standard_normal((B, 1, 256)).astype(np.float32)
+
+    class EpsModel:                      # the EgoHMR model interface returns pred_x_start; ours predicts epsilon
+        def __init__(self, d, eps):
+            self.d, self.eps = d, torch.from_numpy(eps)
+
+        def __call__(self, batch, t):
+            return {"pred_x_start": self.d._predict_xstart_from_eps(batch["x_t"], t, self.eps)}
+
+    out = dict(x=x, eps=eps, ddim_t=np.array([981, 501, 21, 1], np.int64))
+    for t in out["ddim_t"]:
+        idx = torch.full((B,), int((t - 1) // 20 + 1), dtype=torch.long)
+        for eta in (0.0, 0.5):
+            torch.manual_seed(100 + int(t))
+            noise = torch.randn(B, 1, 256)                             # ddim_sample draws th.randn_like(x) once
+            torch.manual_seed(100 + int(t))
+            r = gd.ddim_sample(EpsModel(gd, eps), {}, torch.from_numpy(x), idx, clip_denoised=False, eta=eta)
+            out[f"ddim_t{t}_eta{eta}"] = r["sample"].numpy()
+            out[f"ddim_noise_t{t}"] = noise.numpy()
+    # DDPM ancestral step and forward noising on the full 1000-step schedule (modules_novae/scheduler.yaml:16-26: fixed_small)
+    gd2 = GaussianDiffusion(betas=1.0 - acp / np.concatenate([[1.0], acp[:-1]]))
+    out["ddpm_t"] = np.array([999, 500, 1, 0], np.int64)
+    for t in out["ddpm_t"]:
+        idx = torch.full((B,), int(t), dtype=torch.long)
+        torch.manual_seed(200 + int(t))
+        noise = torch.randn(B, 1, 256)
+        torch.manual_seed(200 + int(t))
+        r = gd2.p_sample(EpsModel(gd2, eps), {}, torch.from_numpy(x), idx, clip_denoised=False)
+        out[f"ddpm_t{t}"] = r["sample"].numpy()
+        out[f"ddpm_noise_t{t}"] = noise.numpy()
+    tv = np.array([999, 0, 37, 512], np.int64)
+    out["add_noise_t"] = tv
+    out["add_noise"] = gd2.q_sample(torch.from_numpy(x), torch.from_numpy(tv), noise=torch.from_numpy(eps)).numpy()
+    save("schedulers_egohmr.npz", **out)
+
+
 if __name__ == "__main__":
     vae_case("vae_F132_T24.npz", 132, 24, [24, 17, 9], with_layers=True)
     vae_case("vae_F75_T60.npz", 75, 60, [60, 60])
@@ -170,3 +271,5 @@ if __name__ == "__main__":
     loop_case("ddim50_N1_B3.npz", 1, 3, 50)
     loop_case("ddim10_N2_B2_cfg.npz", 2, 2, 10, cfg_scale=7.5)
     misc_case()
+    losses_case()
+    scheduler_case()

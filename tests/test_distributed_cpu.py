@@ -33,11 +33,27 @@ def _worker(rank, ws, port, q):
     x = torch.full((3, 8), float(rank + 1))
     lin(x).sum().backward()
     n = D.allreduce_gradients(params)
+    # 2b) the training loop's form: gradients live in ONE flat buffer (views as .grad), reduced in place by one all_reduce
+    lin2 = torch.nn.Linear(8, 4)
+    with torch.no_grad():
+        for a, b in zip(lin2.parameters(), lin.parameters()):
+            a.copy_(b)
+    bucket = D.GradBucket(list(lin2.parameters()))
+    bucket.prepare()
+    ptrs = [p.grad.data_ptr() for p in lin2.parameters()]
+    lin2(x).sum().backward()                               # autograd accumulates into the views in place
+    assert [p.grad.data_ptr() for p in lin2.parameters()] == ptrs
+    nb = bucket.allreduce()
+    bucket.prepare()                                       # next step: the buffer is zeroed, the views stay attached
+    zeroed = float(bucket.flat.abs().max())
+    lin2(x).sum().backward()
+    bucket.allreduce()
     # 3) metric sums
     s = D.reduce_sums(torch.tensor([1.0 + rank, 10.0, 1.0], dtype=torch.float64))
     # plain lists, not tensors: a tensor travels as a file descriptor served by THIS process, and the parent may come for
     # it after this process has exited (FileNotFoundError on the resource-sharer socket, seen once in ~20 runs)
-    q.put((rank, all_ranges, n, lin.weight.grad.tolist(), extra.grad.tolist(), s.tolist()))
+    q.put((rank, all_ranges, n, lin.weight.grad.tolist(), extra.grad.tolist(), s.tolist(), nb, zeroed, lin2.weight.grad.tolist(),
+           lin2.bias.grad.tolist()))
     dist.destroy_process_group()
 
 
@@ -62,6 +78,8 @@ def test_world2_gloo():
         assert torch.allclose(torch.tensor(r[3]), torch.full((4, 8), 4.5))
         assert torch.equal(torch.tensor(r[4]), torch.zeros(5))
         assert torch.allclose(torch.tensor(r[5], dtype=torch.float64), torch.tensor([3.0, 20.0, 2.0], dtype=torch.float64))
+        assert r[6] == 8 * 4 + 4 and r[7] == 0.0
+        assert torch.allclose(torch.tensor(r[8]), torch.full((4, 8), 4.5)) and torch.allclose(torch.tensor(r[9]), torch.full((4,), 3.0))
 
 
 def test_single_process_is_identity():
@@ -72,3 +90,20 @@ def test_single_process_is_identity():
     p.grad = torch.ones(3) * 2
     D.allreduce_gradients([p])
     assert torch.equal(p.grad, torch.ones(3) * 2)
+
+
+def test_bench_starts_its_own_ranks_before_touching_the_gpu():
+    """`python bench.py --gpus 2` with no launcher in the environment: the parent starts two rank processes (RANK /
+    WORLD_SIZE / MASTER_* set) and never initialises the GPU itself.  Without a GPU every rank stops at the product's
+    "needs an MI355X" guard -- which names its rank -- and the parent returns their failure."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check of the launcher (the GPU rehearsal runs bench.py --gpus 2 for real)")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "rank 0 of 2" in r.stderr and "rank 1 of 2" in r.stderr, r.stderr

@@ -1,0 +1,334 @@
+"""GPU parity of the ORCHESTRATION (seeme_amd.mld.MLD on the HIP path) against the flow oracle (oracle/mld_flows.py),
+with every random draw injected: stage-2 forward with classifier-free masks (a20), stage-1 forward and losses (a21, a24),
+ego_eval in its 'vae' / classifier-free / rot6d / GIMO forms (a22, f4), the GIMO configuration (BASELINE configs[3]),
+and the training-step plumbing (flat gradient bucket, graph-captured step)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, rel_err
+from oracle import mld_flows as F
+from oracle import mld_oracle as O
+from seeme_amd import shapes
+from seeme_amd.weights_recipe import load_recipe_, recipe_state_dict
+
+pytestmark = pytest.mark.gpu
+TOL_F32 = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _mld(dev, cfg_name, T=16, n_points=384, mutate=None):
+    from seeme_amd.config import parse_config
+    from seeme_amd.mld import MLD, SyntheticEgoDataModule
+    from seeme_amd.smpl import SMPL
+    cfg = parse_config(os.path.join(REPO, "configs", cfg_name))
+    if mutate:
+        mutate(cfg)
+    dm = SyntheticEgoDataModule(nfeats=cfg.model.nfeats, T=T, n_points=n_points, device=dev,
+                                pose_dim=cfg.model.nfeats - (3 if cfg.TRAIN.ABLATION.PREDICT_TRANSL else 0))
+    torch.manual_seed(7)                                    # output_scene keeps torch's init: make it reproducible
+    model = MLD(cfg, dm, smpl_model=SMPL.synthetic(1234))
+    load_recipe_(model.vae), load_recipe_(model.denoiser)
+    if hasattr(model, "proscene"):
+        load_recipe_(model.proscene.scene_enc)
+    return model.to(dev), dm, cfg
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _oracle_params(model, nfeats):
+    Pv, Pd = recipe_state_dict(shapes.vae_shapes(nfeats)), recipe_state_dict(shapes.denoiser_shapes())
+    Ppn = recipe_state_dict(shapes.pointnet_shapes())
+    Pos = {k: _np(v) for k, v in model.output_scene.state_dict().items()} if hasattr(model, "output_scene") else None
+    return Pv, Pd, Ppn, Pos
+
+
+def _gen(seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    return lambda *shape: torch.randn(*shape, generator=g).to(dev), lambda p, *shape: (torch.rand(*shape, generator=g) < p).to(dev)
+
+
+# ----------------------------------------------------------------------------- a20: stage-2 forward, injected draws
+@pytest.mark.parametrize("cfg_name,guidance", [("config_mld_scene.yaml", 7.5), ("config_mld_gimo.yaml", 1.0),
+                                               ("config_mld_egobody.yaml", 1.0)])
+def test_train_diffusion_forward_vs_oracle(dev, cfg_name, guidance):
+    """train_diffusion_forward (mld.py:887-1017 + 582-631): batch unpack by condition, classifier-free INPUT masks on
+    scene points and interactee features, the two frozen-VAE samples, condition assembly [z_cond, scene], add_noise and
+    the denoiser -- against the oracle chain on identical inputs, masks and noises.  config_mld_gimo = BASELINE
+    configs[3]'s model: nfeats 69, scene-only condition (N = 1)."""
+    def mut(cfg):
+        cfg.model.guidance_scale = guidance
+    model, dm, cfg = _mld(dev, cfg_name, mutate=mut)
+    model.eval()                                             # (eval: no dropout anywhere; the forward is the training one)
+    B, T, nf = 3, 16, cfg.model.nfeats
+    with_scene = "scene" in cfg.model.condition
+    batch = dm.batch(B, idx=5, with_scene=with_scene)
+    assert batch[0].shape[-1] == nf - 3
+    rn, rm = _gen(21, dev)
+    eps_z, eps_c, noise = rn(1, B, 256), rn(1, B, 256), rn(B, 1, 256)
+    ts = torch.tensor([999, 0, 417], device=dev)
+    m_scene = rm(0.1, B, dm.n_points, 3) if with_scene else None
+    m_int = rm(0.1, B, T, nf)
+    with torch.no_grad():
+        rs = model.train_diffusion_forward(batch, noise=noise, timesteps=ts, eps=(eps_z, eps_c), masks=(m_scene, m_int))
+    Pv, Pd, Ppn, Pos = _oracle_params(model, nf)
+    want = F.train_diffusion_forward(
+        Pv, Pd, _np(batch[0]), _np(batch[1]), condition=tuple(cfg.model.condition), eps_z=_np(eps_z), eps_c=_np(eps_c),
+        noise=_np(noise), timesteps=_np(ts), scene=_np(batch[4]) if with_scene else None, Ppn=Ppn, Pos=Pos,
+        mask_scene=_np(m_scene) if with_scene else None, mask_int=_np(m_int), guidance_scale=guidance)
+    n_tokens = len([c for c in cfg.model.condition if c in ("scene", "interactee")])
+    assert want["cond_emb"].shape[0] == n_tokens
+    assert rel_err(_np(rs["noise_pred"]), want["noise_pred"]) < 2 * TOL_F32
+    loss = float(model.losses["train"].update(rs, accumulate=False))
+    assert abs(loss - F.mld_losses(want, "diffusion", {"LAMBDA_REC": 1.0})["total"]) < 1e-4 * max(1.0, loss)
+    if guidance > 1.0:      # the masks matter: without them the prediction changes
+        with torch.no_grad():
+            rs2 = model.train_diffusion_forward(batch, noise=noise, timesteps=ts, eps=(eps_z, eps_c),
+                                                masks=(torch.zeros_like(m_scene), torch.zeros_like(m_int)))
+        assert rel_err(_np(rs2["noise_pred"]), want["noise_pred"]) > 1e-3
+
+
+# ----------------------------------------------------------------------------- a21 / a24: stage-1 forward and losses
+@pytest.mark.parametrize("cfg_name", ["config_vae_egobody.yaml", "config_vae_gimo.yaml"])
+def test_train_vae_forward_and_losses_vs_oracle(dev, cfg_name):
+    """train_vae_forward (mld.py:633-885) and MLDLosses.update (losses/mld.py:113-156) with non-unit lambdas: renormed
+    m_ref / m_rst, SMPL joints ([:21] and the reference's global orientation for GIMO), SmoothL1 / KL terms, total --
+    on the no-grad HIP path and on the differentiable path used for training."""
+    def mut(cfg):
+        cfg.LOSS.LAMBDA_KL, cfg.LOSS.LAMBDA_REC, cfg.LOSS.LAMBDA_JOINT, cfg.LOSS.LAMBDA_ROOT = 3e-3, 0.7, 1.9, 0.31
+    model, dm, cfg = _mld(dev, cfg_name, mutate=mut)
+    B, nf = 3, cfg.model.nfeats
+    dataset = cfg.DATASET_NAME
+    batch = dm.batch(B, idx=2)
+    rn, _ = _gen(4, dev)
+    eps = rn(1, B, 256)
+    Pv = recipe_state_dict(shapes.vae_shapes(nf))
+    smpl = O.make_synthetic_smpl(1234)
+    want = F.train_vae_forward(Pv, smpl, _np(batch[0]), _np(batch[1]), _np(batch[2]), _np(dm.mean), _np(dm.std), _np(eps),
+                               dataset=dataset)
+    lam = {k: float(cfg.LOSS[k]) for k in ("LAMBDA_KL", "LAMBDA_REC", "LAMBDA_JOINT", "LAMBDA_ROOT")}
+    wl = F.mld_losses(want, "vae", lam)
+    nj = 21 if dataset == "gimo" else 24
+    for grad in (False, True):
+        model.train(grad)
+        model.vae.eval()                                     # dropout off: parity needs the deterministic forward
+        with torch.set_grad_enabled(grad):
+            rs = model.train_vae_forward(batch, eps=eps)
+            assert rs["joints_rst"].shape == (B, 16, nj, 3)
+            assert rel_err(_np(rs["m_rst"]), want["m_rst"]) < 2 * TOL_F32 and rel_err(_np(rs["m_ref"]), want["m_ref"]) < 1e-6
+            assert rel_err(_np(rs["joints_ref"]), want["joints_ref"]) < TOL_F32
+            assert rel_err(_np(rs["joints_rst"]), want["joints_rst"]) < 5 * TOL_F32
+            L = model.losses["train"]
+            L.reset()
+            total = float(L.update(rs))
+        got = L.compute()
+        for k in ("recons_feature", "recons_joints", "recons_transl", "kl_motion"):
+            assert abs(got[k] - wl[k]) < 5e-4 * max(1e-3, abs(wl[k])), (grad, k, got[k], wl[k])
+        assert abs(total - wl["total"]) < 5e-4 * abs(wl["total"]), (grad, total, wl["total"])
+
+
+# ----------------------------------------------------------------------------- ego_eval forms
+def test_ego_eval_vae_stage_validation_and_test_steps(dev):
+    """STAGE vae (configs/config_vae_egobody.yaml, condition [text]): ego_eval encodes the target motion and decodes it
+    (mld.py:1328-1360) -- no condition tokens, no reverse diffusion -- and validation_step / test_step score that."""
+    model, dm, cfg = _mld(dev, "config_vae_egobody.yaml")
+    model.eval()
+    B = 3
+    lengths = [16, 11, 16]
+    batch = dm.batch(B, idx=9, lengths=lengths)
+    rn, _ = _gen(8, dev)
+    eps = rn(1, B, 256)
+    rs = model.ego_eval(batch, cond_noise=eps)
+    Pv = recipe_state_dict(shapes.vae_shapes(75))
+    want = F.ego_eval(Pv, None, O.make_synthetic_smpl(1234), _np(batch[0]), _np(batch[1]), _np(batch[2]), lengths,
+                      _np(dm.mean), _np(dm.std), stage="vae", eps_c=_np(eps))
+    assert rel_err(_np(rs["m_rst"]), want["m_rst"]) < 2 * TOL_F32
+    assert rel_err(_np(rs["joints_rst"]), want["joints_rst"]) < 5 * TOL_F32
+    model.EgoMetric.reset()
+    loss = model.validation_step(batch)                      # 'val': loss of train_vae_forward + metrics of ego_eval
+    assert torch.isfinite(loss)
+    model.EgoMetric.reset()
+    torch.manual_seed(3)
+    out = model.test_step(batch)
+    assert out.shape == (B, 16, 24, 3) and np.isfinite(model.EgoMetric.compute()["MPJPE"])
+    # metrics of the deterministic reconstruction vs the oracle's
+    model.sample_mean = True
+    model.EgoMetric.reset()
+    model.validation_step(batch)
+    got = model.EgoMetric.compute()
+    wm = F.ego_eval(Pv, None, O.make_synthetic_smpl(1234), _np(batch[0]), _np(batch[1]), _np(batch[2]), lengths,
+                    _np(dm.mean), _np(dm.std), stage="vae", eps_c=np.zeros((1, B, 256), np.float32))
+    m = O.ego_metrics(wm["joints_rst"].astype(np.float64), wm["joints_ref"].astype(np.float64), wm["orientation_quat_rst"].astype(np.float64),
+                      wm["orientation_quat_ref"].astype(np.float64), lengths, "val")
+    assert abs(got["MPJPE"] - m["MPJPE"]) < 1e-3 * max(1.0, m["MPJPE"])
+
+
+def test_ego_eval_cfg_scene_reference_order_vs_oracle(dev):
+    """Classifier-free guidance with scene + interactee (mld.py:1144-1158, 1283-1290, 489): interactee tokens
+    [uncond, cond], scene tokens [cond, uncond] -- the reference's layout, reproduced by default -- vs the oracle; the
+    opt-in TEST.CFG_SCENE_ORDER 'fixed' differs."""
+    def mut(cfg):
+        cfg.model.guidance_scale = 2.5
+        cfg.model.scheduler.num_inference_timesteps = 10
+    model, dm, cfg = _mld(dev, "config_mld_scene.yaml", mutate=mut)
+    model.eval()
+    B, lengths = 2, [16, 16]
+    batch = dm.batch(B, idx=4, with_scene=True)
+    rn, _ = _gen(15, dev)
+    lat, e_c, e_u = rn(B, 1, 256), rn(1, B, 256), rn(1, B, 256)
+    rs = model.ego_eval(batch, latents=lat, cond_noise=(e_c, e_u))
+    Pv, Pd, Ppn, Pos = _oracle_params(model, 75)
+    want = F.ego_eval(Pv, Pd, O.make_synthetic_smpl(1234), _np(batch[0]), _np(batch[1]), _np(batch[2]), lengths, _np(dm.mean),
+                      _np(dm.std), condition=("text", "scene", "interactee"), latents=_np(lat), eps_c=_np(e_c), eps_u=_np(e_u),
+                      scene=_np(batch[4]), Ppn=Ppn, Pos=Pos, guidance_scale=2.5, steps=10)
+    assert rel_err(_np(rs["lat_t"]), want["lat_t"]) < 5 * TOL_F32
+    assert rel_err(_np(rs["joints_rst"]), want["joints_rst"]) < 1e-3
+    model.cfg_scene_order = "fixed"
+    rs_fixed = model.ego_eval(batch, latents=lat, cond_noise=(e_c, e_u))
+    assert rel_err(_np(rs_fixed["lat_t"]), want["lat_t"]) > 1e-3
+
+
+def test_ego_eval_rot6d_vs_oracle(dev):
+    """DATA_TYPE rot6d (mld.py:161-163, 1410-1449): 24 x 6 features -> rotation matrices -> SMPL with pose2rot=False, no
+    betas / translation; the reference builds that body model in float64, the HIP layer is fp32 (tolerance 1e-4)."""
+    def mut(cfg):
+        cfg.DATA_TYPE = "rot6d"
+        cfg.model.nfeats = 144
+        cfg.TRAIN.ABLATION.PREDICT_TRANSL = False
+        cfg.model.scheduler.num_inference_timesteps = 5
+    model, dm, cfg = _mld(dev, "config_mld_egobody.yaml", mutate=mut)
+    model.eval()
+    B, lengths = 2, [16, 13]
+    batch = dm.batch(B, idx=6, lengths=lengths)
+    assert batch[0].shape[-1] == 144
+    rn, _ = _gen(2, dev)
+    lat, e_c = rn(B, 1, 256), rn(1, B, 256)
+    rs = model.ego_eval(batch, latents=lat, cond_noise=e_c)
+    Pv, Pd = recipe_state_dict(shapes.vae_shapes(144)), recipe_state_dict(shapes.denoiser_shapes())
+    want = F.ego_eval(Pv, Pd, O.make_synthetic_smpl(1234), _np(batch[0]), _np(batch[1]), _np(batch[2]), lengths, _np(dm.mean),
+                      _np(dm.std), latents=_np(lat), eps_c=_np(e_c), data_type="rot6d", predict_transl=False, steps=5)
+    assert rs["orientation_quat_rst"] is None and rs["joints_rst"].shape == (B, 16, 24, 3)
+    assert rel_err(_np(rs["m_rst"]), want["m_rst"]) < 5 * TOL_F32
+    assert rel_err(_np(rs["joints_ref"]), want["joints_ref"]) < TOL_F32
+    assert rel_err(_np(rs["joints_rst"]), want["joints_rst"]) < 1e-3
+
+
+def test_gimo_config_eval_and_training_step(dev):
+    """config_mld_gimo (BASELINE configs[3]): 69 features (root + 21 joints + translation, padded to SMPL's 23 joints),
+    scene-only condition (one token: the tabulated ca_block path of the kernel), ego_eval keeps 24 joints and the
+    predicted orientation (mld.py:1655-1745); a few optimiser steps through the flat gradient bucket reduce the loss."""
+    def mut(cfg):
+        cfg.model.scheduler.num_inference_timesteps = 10
+        cfg.TRAIN.OPTIM.LR = 1e-3
+    model, dm, cfg = _mld(dev, "config_mld_gimo.yaml", mutate=mut)
+    assert model.vae.nfeats == 69 and list(cfg.model.condition) == ["text", "scene"]
+    model.eval()
+    B, lengths = 3, [16, 16, 9]
+    batch = dm.batch(B, idx=1, with_scene=True, lengths=lengths)
+    rn, _ = _gen(31, dev)
+    lat = rn(B, 1, 256)
+    rs = model.ego_eval(batch, latents=lat)
+    Pv, Pd, Ppn, Pos = _oracle_params(model, 69)
+    want = F.ego_eval(Pv, Pd, O.make_synthetic_smpl(1234), _np(batch[0]), _np(batch[1]), _np(batch[2]), lengths, _np(dm.mean),
+                      _np(dm.std), condition=("text", "scene"), latents=_np(lat), scene=_np(batch[4]), Ppn=Ppn, Pos=Pos,
+                      dataset="gimo", steps=10)
+    assert rs["joints_rst"].shape == (B, 16, 24, 3)
+    assert rel_err(_np(rs["lat_t"]), want["lat_t"]) < 5 * TOL_F32
+    assert rel_err(_np(rs["joints_rst"]), want["joints_rst"]) < 1e-3
+    model.EgoMetric.reset()
+    model.test_step(batch)
+    assert np.isfinite(model.EgoMetric.compute()["MPJPE"])
+    # training: scene-only condition through the HIP backward, gradients in one flat buffer
+    model.train()
+    tb = dm.batch(4, idx=3, with_scene=True)
+    g = torch.Generator().manual_seed(11)
+    noise, ts = torch.randn(4, 1, 256, generator=g).to(dev), torch.randint(0, 1000, (4,), generator=g).to(dev)
+    eps = (torch.randn(1, 4, 256, generator=g).to(dev), None)
+    losses = []
+    for _ in range(8):
+        loss = model.losses["train"].update(model.train_diffusion_forward(tb, noise=noise, timesteps=ts, eps=eps))
+        model.optimizer_step(loss)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    bucket = model.grad_bucket()
+    assert bucket.n_pack > 0 and all(p.grad.data_ptr() == bucket.views[id(p)].data_ptr() for p in bucket.params)
+    lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + 4 * bucket.flat.numel()
+    off_path = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+    assert off_path == ["denoiser.mem_pos.pe"]                 # never used by trans_enc: no gradient, never decayed
+    assert all(lo <= p.grad.data_ptr() < hi for p in model.trainable_parameters() if p.grad is not None)
+    assert bucket.flat.numel() == sum(p.numel() for p in model.trainable_parameters() if p.grad is not None)
+
+
+# ----------------------------------------------------------------------------- training-step plumbing
+def test_grad_bucket_step_equals_separate_gradients(dev):
+    """optimizer_step (flat bucket: views as .grad, HIP backward writing its block in place, one-launch AdamW) gives the
+    same parameters as the plain path (zero_grad, backward into separate tensors, torch.optim.AdamW.step)."""
+    res = []
+    for bucketed in (True, False):
+        model, dm, cfg = _mld(dev, "config_mld_scene.yaml")
+        model.train()
+        tb = dm.batch(4, idx=3, with_scene=True)
+        g = torch.Generator().manual_seed(5)
+        noise, ts = torch.randn(4, 1, 256, generator=g).to(dev), torch.randint(0, 1000, (4,), generator=g).to(dev)
+        eps = (torch.randn(1, 4, 256, generator=g).to(dev), torch.randn(1, 4, 256, generator=g).to(dev))
+        model.configure_optimizers()
+        for _ in range(3):
+            loss = model.losses["train"].update(model.train_diffusion_forward(tb, noise=noise, timesteps=ts, eps=eps))
+            if bucketed:
+                model.optimizer_step(loss)
+            else:
+                model.optimizer.zero_grad(set_to_none=True)
+                loss.backward()
+                model.optimizer.step()
+        res.append({k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad})
+    worst = max(rel_err(_np(res[0][k]), _np(res[1][k])) for k in res[0])
+    assert worst < 2e-5, worst
+
+
+def test_capture_training_step_replay_equals_eager(dev):
+    """capture_training_step: the stage-2 step as one hipGraph (frozen encoders, denoiser forward + backward, in-graph
+    one-launch AdamW whose step count and learning rate live on the device).  An optimiser already exists before the
+    capture (the case ADVICE r1 flagged); every replay must advance the step counts on both sides and apply exactly
+    the AdamW update of the gradients it left in the flat bucket, including after an LR-scheduler edit."""
+    model, dm, cfg = _mld(dev, "config_mld_egobody.yaml")
+    model.train()
+    tb = dm.batch(4, idx=3)
+    model.configure_optimizers()
+    loss = model.training_step(tb)
+    model.optimizer_step(loss)                                 # eager steps first: optimiser state exists ...
+    model.optimizer_step(model.training_step(tb))              # ... and so does the gradient bucket; step = 2
+    replay = model.capture_training_step(tb, warmup=1)         # + 1 warm-up step
+    torch.cuda.synchronize()
+    bucket = model.grad_bucket()
+    opt = model.optimizer
+    for it in range(3):
+        if it == 2:
+            opt.param_groups[0]["lr"] = 0.5 * opt.param_groups[0]["lr"]         # what StepLR does at an epoch end
+        p0 = {id(p): p.detach().clone() for p in bucket.params}
+        m0 = {id(p): opt.state[p]["exp_avg"].clone() for p in bucket.params}
+        v0 = {id(p): opt.state[p]["exp_avg_sq"].clone() for p in bucket.params}
+        t = float(opt.state[bucket.params[0]]["step"]) + 1.0
+        loss = replay()
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss)
+        assert float(opt.state[bucket.params[0]]["step"]) == t == 4.0 + it
+        assert float(list(model._fused_adamw._dev_scalars.values())[0][0]) == t
+        lr, (b1, b2), eps_, wd = (opt.param_groups[0][k] for k in ("lr", "betas", "eps", "weight_decay"))
+        worst = 0.0
+        for p in bucket.params:
+            gth = bucket.views[id(p)].double()
+            m = m0[id(p)].double() * b1 + (1 - b1) * gth
+            v = v0[id(p)].double() * b2 + (1 - b2) * gth * gth
+            want = p0[id(p)].double() * (1 - lr * wd) - lr / (1 - b1 ** t) * m / (v.sqrt() / (1 - b2 ** t) ** 0.5 + eps_)
+            worst = max(worst, float((p.detach().double() - want).abs().max() / want.abs().max().clamp_min(1e-12)))
+        assert worst < 1e-5, (it, worst)
+        assert float(bucket.flat.abs().max()) > 0

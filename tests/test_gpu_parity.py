@@ -330,15 +330,18 @@ def test_mld_sample_vs_oracle_mpjpe(dev):
     model, dm, cfg = _mld(dev, T=24)
     B = 3
     batch = dm.batch(B, idx=1)
-    lat = torch.randn(B, 1, 256, generator=torch.Generator().manual_seed(5)).to(dev)
-    rs = model.ego_eval(batch, latents=lat)
+    gen = torch.Generator().manual_seed(5)
+    lat = torch.randn(B, 1, 256, generator=gen).to(dev)
+    eps_c = torch.randn(1, B, 256, generator=gen).to(dev)     # the condition is a SAMPLE of the posterior (mld.py:1280)
+    rs = model.ego_eval(batch, latents=lat, cond_noise=eps_c)
     # oracle
     Pv, Pd = recipe_state_dict(shapes.vae_shapes(75)), recipe_state_dict(shapes.denoiser_shapes())
     motion, transl, beta = (t.cpu().numpy() for t in batch[:3])
     lengths = [24] * B
     f_int = np.concatenate([motion[:, :, 1], transl[:, 1]], -1)
-    mu, _ = O.vae_encode(Pv, f_int, lengths)
-    z = O.diffusion_reverse(Pd, np.transpose(mu, (1, 0, 2)), lat.cpu().numpy(), 50)
+    mu, sd = O.vae_encode(Pv, f_int, lengths)
+    z_cond = mu + eps_c.cpu().numpy() * sd
+    z = O.diffusion_reverse(Pd, np.transpose(z_cond, (1, 0, 2)), lat.cpu().numpy(), 50)
     feats = O.renorm(O.vae_decode(Pv, z, lengths), dm.mean.cpu().numpy(), dm.std.cpu().numpy())
     smpl = O.make_synthetic_smpl(1234)
     j, _ = O.smpl_lbs(smpl, beta[:, 0].reshape(-1, 10), feats[..., :3].reshape(-1, 3), feats[..., 3:72].reshape(-1, 69),
@@ -372,7 +375,7 @@ def test_mld_sample_vs_oracle_mpjpe(dev):
     # not held to the fp32 gate
     model.denoiser.weight_dtype = "fp16"
     model.vae.precision = "fp16"
-    rs16 = model.ego_eval(batch, latents=lat)
+    rs16 = model.ego_eval(batch, latents=lat, cond_noise=eps_c)
     m16 = O.ego_metrics(rs16["joints_rst"].double().cpu().numpy(), rs16["joints_ref"].double().cpu().numpy(),
                         rs16["orientation_quat_rst"].double().cpu().numpy(), rs16["orientation_quat_ref"].double().cpu().numpy(),
                         rs16["lengths"], "val")

@@ -230,3 +230,34 @@ def test_ego_metrics_match_reference_loops(split):
     assert got["count_seq"] == want["count_seq"] and 0 < got["count_seq"] < B
     for k in ("MPJPE", "ROOT_ERROR", "ACCL", "HEAD_ORIENTATION_ERROR"):
         assert abs(got[k] - want[k]) <= 2e-4 * max(1.0, abs(want[k])), (k, got[k], want[k])
+
+
+# ----------------------------------------------------------------------------- SMPL model files
+def test_smpl_pkl_loader_is_code_free(tmp_path):
+    """A user-supplied SMPL_*.pkl is read with an allow-listing unpickler: arrays and sparse matrices load, any other
+    global (the way a pickle executes code) is refused."""
+    import pickle
+    import scipy.sparse as sp
+    from seeme_amd import smpl as S
+    V = 40
+    rng = np.random.default_rng(0)
+    d = {"v_template": rng.standard_normal((V, 3)), "shapedirs": rng.standard_normal((V, 3, 10)),
+         "posedirs": rng.standard_normal((V, 3, 207)), "J_regressor": sp.csc_matrix(rng.random((24, V))),
+         "weights": rng.random((V, 24)), "kintree_table": np.stack([np.array(S.SMPL_PARENTS, np.int64) % (2 ** 32), np.arange(24)]),
+         "f": np.zeros((5, 3), np.uint32)}
+    good = tmp_path / "SMPL_NEUTRAL.pkl"
+    good.write_bytes(pickle.dumps(d, protocol=2))
+    out = S._load_model_file(str(tmp_path))
+    assert out["J_regressor"].shape == (24, V) and out["posedirs"].shape == (207, V * 3) and out["parents"][0] == -1
+    np.testing.assert_allclose(out["v_template"], d["v_template"].astype(np.float32))
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > " + str(tmp_path / "pwned"),))
+
+    bad = tmp_path / "bad.pkl"
+    bad.write_bytes(pickle.dumps({"v_template": Evil()}, protocol=2))
+    with pytest.raises(pickle.UnpicklingError):
+        S._load_model_file(str(bad))
+    assert not (tmp_path / "pwned").exists()
