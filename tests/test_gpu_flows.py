@@ -203,6 +203,7 @@ def test_ego_eval_rot6d_vs_oracle(dev):
     def mut(cfg):
         cfg.DATA_TYPE = "rot6d"
         cfg.model.nfeats = 144
+        cfg.model.motion_vae.params.nfeats = cfg.model.denoiser.params.nfeats = 144   # (${model.nfeats} is resolved at parse)
         cfg.TRAIN.ABLATION.PREDICT_TRANSL = False
         cfg.model.scheduler.num_inference_timesteps = 5
     model, dm, cfg = _mld(dev, "config_mld_egobody.yaml", mutate=mut)
