@@ -1,0 +1,80 @@
+"""Debug: which part of the stage-2 training step survives hipGraph capture (each stage in a child process)."""
+import os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+STAGES = ["vae_encode", "forward_nograd", "forward", "fwd_bwd_twin", "fwd_bwd", "fwd_bwd_bucket", "adamw_only", "full"]
+
+
+def child(stage):
+    import torch
+    from seeme_amd.config import parse_config
+    from seeme_amd.mld import MLD, SyntheticEgoDataModule
+    from seeme_amd.smpl import SMPL
+    from seeme_amd.weights_recipe import load_recipe_
+    dev = torch.device("cuda", 0)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = parse_config(os.path.join(repo, "configs", "config_mld_egobody.yaml"))
+    if stage == "fwd_bwd_twin":
+        cfg.TRAIN.HIP_BACKWARD = False
+    dm = SyntheticEgoDataModule(nfeats=75, T=16, device=dev)
+    model = MLD(cfg, dm, smpl_model=SMPL.synthetic(1234))
+    load_recipe_(model.vae), load_recipe_(model.denoiser)
+    model = model.to(dev).train()
+    tb = dm.batch(4, idx=3)
+    model.configure_optimizers()
+    for _ in range(3):
+        model.optimizer_step(model.training_step(tb))
+    torch.cuda.synchronize()
+    losses = model.losses["train"]
+    fused = model._fused_adamw
+
+    def body():
+        if stage == "vae_encode":
+            f = model._wearer_features(tb[0].float(), tb[1].float(), 0)
+            return model.vae.encode_dist(f, [16] * 4).sum()
+        if stage == "forward_nograd":
+            with torch.no_grad():
+                return losses.update(model.train_diffusion_forward(tb), accumulate=False)
+        loss = losses.update(model.train_diffusion_forward(tb), accumulate=False)
+        if stage == "forward":
+            return loss.detach()
+        if stage in ("fwd_bwd", "fwd_bwd_twin"):
+            for p in model.trainable_parameters():
+                p.grad = None
+            loss.backward()
+            return loss.detach()
+        if stage == "fwd_bwd_bucket":
+            model.backward(loss)
+            return loss.detach()
+        if stage == "adamw_only":
+            fused.step(device_step=True)
+            return loss.detach()
+        model.backward(loss)
+        fused.step(device_step=True)
+        return loss.detach()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = body()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    print(f"stage {stage}: OK, value {float(out):.6f}", flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        child(sys.argv[1])
+    else:
+        for s in STAGES:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), s], capture_output=True, text=True, timeout=300)
+            tail = (r.stdout.strip().splitlines() or [""])[-1]
+            err = [l for l in r.stderr.splitlines() if "Error" in l or "error" in l or "fault" in l.lower()][:3]
+            print(f"{s}: rc={r.returncode} {tail} {err}", flush=True)
