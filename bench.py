@@ -152,6 +152,38 @@ def cpu_baseline(B, budget_s=12.0):
                       + ", ".join(f"{k}t {v:.2f}" for k, v in trials.items()) + ")"}
 
 
+def mpjpe_check(dev, weights, vae_prec, B):
+    """north_star's accuracy gate for the throughput mode: config_mld_egobody (interactee-only, nfeats 75, so that the
+    decoded features are SMPL parameters), B sequences of T=196, the same inputs / initial latents / condition noise
+    through (a) the fp32 parity path -- pinned to the oracle within 1e-5 mm by tests/test_gpu_parity.py -- and (b) the
+    precision mode this run is timed in; MPJPE of each against the synthetic ground truth (metrics/compute.py alignment),
+    their difference (the gate: 1e-3 mm) and the mean joint-to-joint distance between the two outputs."""
+    from seeme_amd.config import parse_config
+    from seeme_amd.mld import MLD, SyntheticEgoDataModule, EgoMetrics
+    from seeme_amd.smpl import SMPL
+    from seeme_amd.weights_recipe import load_recipe_
+    cfg = parse_config(os.path.join(REPO, "configs", "config_mld_egobody.yaml"))
+    dm = SyntheticEgoDataModule(nfeats=75, T=T_FRAMES, device=dev)
+    model = MLD(cfg, dm, smpl_model=SMPL.synthetic(1234))
+    load_recipe_(model.vae), load_recipe_(model.denoiser)
+    model = model.to(dev).eval()
+    batch = dm.batch(B, idx=1)
+    g = torch.Generator().manual_seed(5)
+    lat, eps = torch.randn(B, 1, 256, generator=g).to(dev), torch.randn(1, B, 256, generator=g).to(dev)
+    out = {}
+    with torch.no_grad():
+        for tag, (wd, vp) in (("fp32", ("fp32", "fp32")), ("mode", (weights, vae_prec))):
+            model.denoiser.weight_dtype, model.vae.precision = wd, vp
+            rs = model.ego_eval(batch, latents=lat, cond_noise=eps)
+            m = EgoMetrics.per_sequence(rs["joints_rst"], rs["joints_ref"], rs["lengths"])["MPJPE"].double().mean().item()
+            out[tag] = (m, rs["joints_rst"])
+    return {"mpjpe_delta_mm": round(abs(out["mode"][0] - out["fp32"][0]), 7), "gate_mm": 1e-3,
+            "mpjpe_fp32_path_mm": round(out["fp32"][0], 6), "mpjpe_this_mode_mm": round(out["mode"][0], 6),
+            "joint_to_joint_mm": round(float((out["mode"][1] - out["fp32"][1]).norm(dim=-1).mean() * 1000.0), 4),
+            "on": f"config_mld_egobody, B={B}, T=196, nfeats=75, synthetic SMPL, same inputs / latents / condition noise; "
+                  "reference = the fp32 HIP path (pinned to the CPU oracle by the gpu tests)"}
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process, which has not
     touched the GPU (no HIP call, no torch.cuda.is_available()) and never will; rank 0 prints the JSON line on the
@@ -296,6 +328,7 @@ def main():
     ap.add_argument("--weights", default="fp16", choices=["fp32", "bf16", "fp16"], help="denoiser weight image dtype")
     ap.add_argument("--vae", default="fp16", choices=["fp32", "fp16"], help="VAE MFMA operand type (fp32 = exact parity path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the MPJPE-vs-fp32-path check and the fp32 timing")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the passes are dealt over (each with its own model instance); 1 = the named configuration, "
                          ">1 = several B-sized batches in flight on one GPU (a B=32 pass occupies 32 of 256 CUs)")
@@ -454,6 +487,18 @@ def main():
                          "per_cu_stream": {"achieved": round(per_cu, 2), "peak": 118.0, "unit": "GB/s per CU",
                                            "frac": round(per_cu / 118.0, 4), "cus_busy": cus}},
         }
+        if world == 1 and S == 1 and not args.graph and args.scheduler == "ddim" and not args.no_parity_check:
+            res["mpjpe_vs_ref"] = mpjpe_check(dev, args.weights, args.vae, B)
+            if not (args.weights == "fp32" and args.vae == "fp32"):      # the parity configuration, timed the same way
+                pv, pd, ps = build_models(dev, "fp32", "fp32")
+                for i in range(args.warmup):
+                    one_pass(pv, pd, ps, motion, latents, lengths)
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                for i in range(args.steps):
+                    one_pass(pv, pd, ps, motion, latents, lengths)
+                torch.cuda.synchronize()
+                res["parity_mode"] = {"dtype": "f32", "value": round(B * args.steps / (time.perf_counter() - tp), 2), "unit": "seqs/s"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(res), flush=True)

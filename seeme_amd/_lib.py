@@ -98,7 +98,7 @@ class PointnetWeights(C.Structure):
 
 
 class PointnetBf16(C.Structure):
-    _fields_ = [("fc0", fp * 4), ("fc1", fp * 4), ("sc", fp * 4), ("posf", fp), ("sc3", fp)]
+    _fields_ = [("fc0", fp * 4), ("fc1", fp * 4), ("sc", fp * 4), ("posf", fp), ("sc3", fp), ("stream", fp * 4), ("sc3f", fp)]
 
 
 GEO_AA_TO_QUAT, GEO_AA_TO_ROTMAT, GEO_QUAT_TO_ROTMAT, GEO_ROT6D_PROHMR, GEO_ROT6D_DIFFUSION = range(5)

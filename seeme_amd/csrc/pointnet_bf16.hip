@@ -16,6 +16,7 @@
 // through fc_pos_0 to a 3 -> 256 map, in the epilogue.  DESIGN.md section 5.2 has the measurements behind each choice.
 #include "common.hpp"
 #include "api_util.hpp"
+#include "pointnet_v2.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef PN_MH_FIRST
@@ -517,7 +518,30 @@ extern "C" int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const S
     SEEME_HIP(hipFuncSetAttribute((const void*)k_pn_block<false, MH_NEXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_next));
     unsigned short* cur = xa;
     unsigned short* nxt = xb;
-    for (int i = 0; i < 4; ++i) {
+    static int use_v2 = -1;
+    if (use_v2 < 0) { const char* e = getenv("SEEME_PN_V2"); use_v2 = (e == nullptr || e[0] != '0') ? 1 : 0; }
+    const bool v2 = use_v2 && wb->stream[0] != nullptr && wb->sc3f != nullptr;
+    for (int i = 0; v2 && i < 4; ++i) {
+        PnBlock2Args a{};
+        a.P = P; a.tiles_x = (P + 255) / 256; a.n_tiles = a.tiles_x * B;
+        a.stream = (const uint4*)wb->stream[i]; a.b0 = w->fc0_b[i]; a.b1 = w->fc1_b[i];
+        a.pool = pools + (size_t)i * B * PN_H;
+        a.out = (i < 3) ? nxt : nullptr;
+        if (i == 0) {
+            a.points = points; a.posf = (const uint2*)wb->posf; a.sc3f = (const uint2*)wb->sc3f;
+        } else {
+            const float* pool_prev = pools + (size_t)(i - 1) * B * PN_H;
+            PnRowsArgs ra{};
+            ra.pool = pool_prev; ra.w[0] = w->fc0_w[i]; ra.w[1] = w->sc_w[i]; ra.y[0] = v0; ra.y[1] = vs; ra.ldy = PN_H;
+            ra.ldw = 512; ra.col0 = PN_H; ra.relu[0] = 1; ra.relu[1] = 0;
+            hipLaunchKernelGGL(k_pn_rows, dim3((unsigned)B, 4), dim3(512), 0, st, ra);
+            if ((rc = seeme_check_launch("k_pn_rows"))) return rc;
+            a.x = cur; a.v0 = v0; a.vs = vs;
+        }
+        if ((rc = seeme_pn_block2_launch(i == 0, a, n_cu, st))) return rc;
+        if (i > 0) { unsigned short* t = cur; cur = nxt; nxt = t; } else { cur = nxt; nxt = xa; }
+    }
+    for (int i = 0; !v2 && i < 4; ++i) {
         PnBlockArgs a{};
         const int mt = 64 * (i == 0 ? MH_FIRST : MH_NEXT), per_cu = 2 / (i == 0 ? MH_FIRST : MH_NEXT);
         a.P = P; a.tiles_x = (P + mt - 1) / mt; a.n_tiles = a.tiles_x * B;

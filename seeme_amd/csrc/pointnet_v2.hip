@@ -1,0 +1,347 @@
+// pointnet_v2.hip -- second generation of the fused ResnetBlockFC kernel (EgoHMR/models/respointnet.py:62-97) for the
+// frozen scene encoder (respointnet.py:33-59; mld/models/modeltype/mld.py:911-922).
+//
+// What bounded the first generation (pointnet_bf16.hip): every wave streamed its own quarter of
+// the block's three weight matrices from L2 for every 64-point tile -- 384 KiB per 64 points per workgroup, i.e. the
+// vector-memory path of a CU (64 B/clk) had to run flat out for the matrix cores to run flat out, and each ran at half.
+// Here the weights of a block are ONE packed stream of 24 slots x 16 KiB (host-packed in the order of use) that a
+// 512-thread workgroup pulls ONCE per 256-point tile into a two-slot LDS ring (16 B/clk of the vector-memory path),
+// and all eight waves read their weight fragments from that ring (ds_read_b128, lane-linear, conflict-free):
+//
+//   wave w owns points [32 w, 32 w + 32) of the tile and ALL 256 features of them, with the weight fragment as the
+//   MFMA A operand and the points as B ("transposed" calls: D[feature][point]):
+//     fc_0        acc0[16 feature tiles][2 point tiles]          K = 256 (block_0: 512), B = relu(x) from registers
+//     hidden      relu(acc0 + b0 + pooled half) -> bf16 B fragments IN REGISTERS: the accumulator layout (lane = point,
+//                 registers = 4 consecutive features) is the B layout of the next product up to a permutation of k, which
+//                 the host applies to fc_1's columns -- the hidden tile never touches LDS, and no barrier separates the GEMMs
+//     out (two halves of 128 features, 64 accumulator registers each):
+//                 acc1 = Ws[half] x (B = raw x) + W1[half] hidden  -> + bias, max-pool, bf16 store
+//   The tile's input rows arrive as B fragments straight from global memory, one k-block (2 x 16 B per lane) per slot, two
+//   slots ahead, through a three-entry register ring: each k-block is fetched three times per tile (fc_0, and the shortcut
+//   of either half; the repeats hit L2) -- keeping the whole tile in registers (64 VGPRs) spilled.
+//   block_0 generates its 512 input features relu(fc_pos_0(p)) per k-block on the matrix cores (split-bf16 operands,
+//   v_mfma_f32_16x16x16_bf16) straight into B fragments, and its shortcut -- folded through fc_pos_0 to a 3 -> 256 map --
+//   is 16 more of those small MFMAs per half into the same accumulator.
+//
+// Per slot a wave issues 32 MFMAs (2 waves per SIMD: 1024 matrix-core cycles), 16 ds_read_b128, 2 global loads and 2
+// ds_write_b128 of the ring, one barrier.  LDS read traffic 128 B/clk per CU (half of its peak), vector-memory traffic
+// about 25 B/clk.  All staging is plain loads + ds_write, so every wait is the compiler's own counted wait.
+#include "common.hpp"
+#include "api_util.hpp"
+#include "pointnet_v2.h"
+
+typedef __bf16 p2_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int p2_u32x4 __attribute__((ext_vector_type(4)));
+typedef short p2_s16x4 __attribute__((ext_vector_type(4)));
+typedef short p2_s16x2 __attribute__((ext_vector_type(2)));
+typedef float p2_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 p2_bf16x2 __attribute__((ext_vector_type(2)));
+
+#define P2_H 256
+#define P2_MT 256                 // points per tile (8 waves x 32)
+#define P2_SLOTS 24               // 16-KiB slots of the weight stream per tile
+#define P2_SLOT_U4 1024           // uint4 per slot
+
+__device__ __forceinline__ float p2_max(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+__device__ __forceinline__ unsigned p2_pack(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(p2_f32x2{lo, hi}, p2_bf16x2));
+}
+// relu on two packed bf16: as signed 16-bit integers negative floats are negative, so it is one v_pk_max_i16 with 0
+__device__ __forceinline__ unsigned p2_relu2(unsigned u) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(p2_s16x2, u), p2_s16x2{0, 0}));
+}
+__device__ __forceinline__ p2_u32x4 p2_relu8(p2_u32x4 v) { return p2_u32x4{p2_relu2(v.x), p2_relu2(v.y), p2_relu2(v.z), p2_relu2(v.w)}; }
+__device__ __forceinline__ void p2_atomic_max(float* p, float v) {
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(p), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned int*>(p), __float_as_uint(v));
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(512, 2) void k_pn_block2(const PnBlock2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS carve (bytes): ring 2 x 16384 | sb0 1024 | sb1 1024 | smax 8 x 1024 | block_0: sposf 16384 | ssc3f 8192
+    uint4* const ring = reinterpret_cast<uint4*>(smem);
+    float* const sb0 = reinterpret_cast<float*>(smem + 32768);
+    float* const sb1 = sb0 + P2_H;
+    float* const smax = sb1 + P2_H;                                   // [8][256]
+    const uint2* const sposf = reinterpret_cast<const uint2*>(smem + 32768 + 2048 + 8192);
+    const uint2* const ssc3f = sposf + 32 * 64;
+
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 15, kq = lane >> 4;
+    const int row0 = wave * 32;
+
+    if (FIRST) {
+        uint2* wp = reinterpret_cast<uint2*>(smem + 32768 + 2048 + 8192);
+        for (int c = tid; c < 32 * 64; c += 512) wp[c] = a.posf[c];
+        for (int c = tid; c < 16 * 64; c += 512) wp[32 * 64 + c] = a.sc3f[c];
+        if (tid < P2_H) { sb0[tid] = a.b0[tid]; sb1[tid] = a.b1[tid]; }
+    }
+
+    // ---- the weight stream: slot q of the tile program = stream[q % 24]; this wave moves 2 KiB of each slot
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.stream), 0, P2_SLOTS * 16384, 0x00020000);
+    const unsigned w_lane = (unsigned)(wave * 2048 + lane * 16);          // byte offset of this lane's 16 B inside a slot (first of two KiB)
+    p2_u32x4 stg[2][2];
+    auto w_load = [&](int slot_in_tile, p2_u32x4 (&dst)[2]) {
+        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, (unsigned)(slot_in_tile * 16384), 0);
+        dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane + 1024u, (unsigned)(slot_in_tile * 16384), 0);
+    };
+    auto w_store = [&](int ring_pos, const p2_u32x4 (&src)[2]) {
+        uint4* d = ring + ring_pos * P2_SLOT_U4 + wave * 128 + lane;
+        d[0] = make_uint4(src[0].x, src[0].y, src[0].z, src[0].w);
+        d[64] = make_uint4(src[1].x, src[1].y, src[1].z, src[1].w);
+    };
+    const uint4* const rl = ring + lane;                                   // fragment f of ring position p: rl[p * 1024 + f * 64]
+
+    // ---- tile range of this workgroup (contiguous: mostly one scene, so the running max stays in a register)
+    const int t0 = (int)(((long long)blockIdx.x * a.n_tiles) / gridDim.x), t1 = (int)(((long long)(blockIdx.x + 1) * a.n_tiles) / gridDim.x);
+    if (t0 >= t1) return;
+    float run_max = -INFINITY;
+    int prev_scene = -1, bias_scene = -1;
+
+    // ---- input of a tile: B fragments in registers.  later blocks: xf[kb][mt] = x[point row0 + 16 mt + r][32 kb + 8 kq .. +7];
+    // block_0: the point as split-bf16 operand pfr[mt] of the small MFMAs
+    p2_u32x4 xr[FIRST ? 1 : 3][2];          // later blocks: x k-block ring, entry = step % 3
+    p2_s16x4 pfr[2];
+    float pxyz[FIRST ? 2 : 1][3];
+    auto tile_rsrc = [&](int tn) {           // buffer over the valid rows of tile tn (rows past the end read as zeros)
+        const int sc = tn / a.tiles_x, q0 = (tn - sc * a.tiles_x) * P2_MT, rv = min(P2_MT, a.P - q0);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x + ((size_t)sc * a.P + q0) * P2_H), 0, rv * P2_H * 2, 0x00020000);
+    };
+    const unsigned x_lane = (unsigned)(((row0 + r) * P2_H + 8 * kq) * 2);
+    auto x_load = [&](const __amdgpu_buffer_rsrc_t& rt, int kb, p2_u32x4 (&dst)[2]) {
+        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rt, x_lane + (unsigned)(kb * 64), 0u, 0);
+        dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rt, x_lane + (unsigned)(kb * 64), (unsigned)(16 * P2_H * 2), 0);
+    };
+    auto issue_pts = [&](int tn) {
+        const int sc = tn / a.tiles_x, q0 = (tn - sc * a.tiles_x) * P2_MT, rv = min(P2_MT, a.P - q0);
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.points + ((size_t)sc * a.P + q0) * 3), 0, rv * 12, 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                pxyz[mt][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (unsigned)((row0 + r) * 12), (unsigned)(mt * 192 + c * 4), 0));
+    };
+    auto make_pfr = [&]() {                   // block_0: (px, py, pz) -> hi/lo split B operand, k slots as SeemePointnetBf16.posf expects
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float px = pxyz[mt][0], py = pxyz[mt][1], pz = pxyz[mt][2];
+            const unsigned hxy = p2_pack(px, py), hz = p2_pack(pz, 0.f) & 0xFFFFu;
+            const unsigned lxy = p2_pack(px - __uint_as_float(hxy << 16), py - __uint_as_float(hxy & 0xFFFF0000u));
+            const unsigned lz = p2_pack(pz - __uint_as_float(hz << 16), 0.f) & 0xFFFFu;
+            const unsigned one = 0x3F80u;
+            const unsigned d0 = kq == 0 ? hxy : kq == 1 ? ((lxy >> 16) | (lz << 16)) : kq == 2 ? (hz | (one << 16)) : 0u;
+            const unsigned d1 = kq == 0 ? (hz | (lxy << 16)) : kq == 1 ? hxy : kq == 2 ? one : 0u;
+            pfr[mt] = __builtin_bit_cast(p2_s16x4, make_uint2(d0, d1));
+        }
+    };
+
+    // ---- prologue: slot 0 into the ring, slot 1 staged, the first tile's input requested
+    w_load(0, stg[0]);
+    w_load(1, stg[1]);
+    __amdgpu_buffer_rsrc_t rx = FIRST ? rs_w : tile_rsrc(t0);
+    if (FIRST) issue_pts(t0);
+    else { x_load(rx, 0, xr[0]); x_load(rx, 1, xr[1]); }
+    w_store(0, stg[0]);
+
+    for (int t = t0; t < t1; ++t) {
+        const int scene = t / a.tiles_x, p0 = (t - scene * a.tiles_x) * P2_MT;
+        const int rows_valid = min(P2_MT, a.P - p0);
+        const bool more = t + 1 < t1;
+        if (FIRST) make_pfr();
+        const bool has_out = a.out != nullptr;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+            has_out ? a.out + ((size_t)scene * a.P + p0) * P2_H : nullptr, 0, has_out ? rows_valid * P2_H * 2 : 0, 0x00020000);
+
+        f32x4 acc0[16][2];
+        p2_u32x4 hf[8][2];
+        f32x4 acc1[8][2];
+#pragma unroll
+        for (int s = 0; s < P2_SLOTS; ++s) {
+            // ---- ring turn: slot s was written one step ago; after the barrier it is readable and the other position is free
+            __syncthreads();
+            if (s + 2 < P2_SLOTS) w_load(s + 2, stg[s & 1]);
+            else if (more) w_load(s + 2 - P2_SLOTS, stg[s & 1]);
+            if (s + 1 < P2_SLOTS || more) w_store((s + 1) & 1, stg[(s + 1) & 1]);
+            const uint4* const rp = rl + (s & 1) * P2_SLOT_U4;
+            if (!FIRST) {                                      // x k-block of step s + 2 (k-block = step % 8), across the tile boundary
+                if (s + 2 == P2_SLOTS && more) rx = tile_rsrc(t + 1);
+                if (s + 2 < P2_SLOTS || more) x_load(rx, (s + 2) % 8, xr[(s + 2) % 3]);
+            }
+
+            if (s == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 16; ++nt) { acc0[nt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc0[nt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                // biases + pooled halves of this tile's scene (later blocks), after the barrier that ended the previous tile's reads
+                if (!FIRST && scene != bias_scene) {
+                    if (tid < P2_H) {
+                        sb0[tid] = a.b0[tid] + a.v0[(size_t)scene * P2_H + tid];
+                        sb1[tid] = a.b1[tid] + a.vs[(size_t)scene * P2_H + tid];
+                    }
+                    bias_scene = scene;
+                }
+            }
+            if (s == 2) {
+                // fold the previous tile's column maxima (written before this tile's first barrier) into the running one
+                if (tid < P2_H && prev_scene >= 0) {
+                    float m = smax[tid];
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) m = p2_max(m, smax[w * P2_H + tid]);
+                    run_max = p2_max(run_max, m);
+                    if (scene != prev_scene) {
+                        p2_atomic_max(a.pool + (size_t)prev_scene * P2_H + tid, run_max);
+                        run_max = -INFINITY;
+                    }
+                }
+                prev_scene = scene;
+            }
+
+            constexpr int S0 = FIRST ? 16 : 8;                 // slots of fc_0
+            if (s < S0) {
+                // ---- fc_0, k-block s: acc0[nt][mt] += W0frag(nt) x relu(x)[mt]
+                p2_u32x4 b[2];
+                if (FIRST) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const f32x4 c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(p2_s16x4, sposf[(2 * s) * 64 + lane]), pfr[mt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        const f32x4 c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(p2_s16x4, sposf[(2 * s + 1) * 64 + lane]), pfr[mt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        b[mt] = p2_relu8(p2_u32x4{p2_pack(c0[0], c0[1]), p2_pack(c0[2], c0[3]), p2_pack(c1[0], c1[1]), p2_pack(c1[2], c1[3])});
+                    }
+                } else {
+                    b[0] = p2_relu8(xr[FIRST ? 0 : s % 3][0]);
+                    b[1] = p2_relu8(xr[FIRST ? 0 : s % 3][1]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 16; ++nt) {
+                    const uint4 w4 = rp[nt * 64];
+                    const p2_bf16x8 wa = __builtin_bit_cast(p2_bf16x8, w4);
+                    acc0[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(p2_bf16x8, b[0]), acc0[nt][0], 0, 0, 0);
+                    acc0[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(p2_bf16x8, b[1]), acc0[nt][1], 0, 0, 0);
+                }
+                if (s == S0 - 1) {
+                    // ---- hidden = relu(acc0 + bias) as the B fragments of fc_1 (k order: see the header; W1 is packed to match)
+#pragma unroll
+                    for (int kb = 0; kb < 8; ++kb) {
+                        const float4 ba = *reinterpret_cast<const float4*>(sb0 + 32 * kb + 4 * kq);
+                        const float4 bb = *reinterpret_cast<const float4*>(sb0 + 32 * kb + 16 + 4 * kq);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            const f32x4 u = acc0[2 * kb][mt], v = acc0[2 * kb + 1][mt];
+                            hf[kb][mt] = p2_relu8(p2_u32x4{p2_pack(u[0] + ba.x, u[1] + ba.y), p2_pack(u[2] + ba.z, u[3] + ba.w),
+                                                           p2_pack(v[0] + bb.x, v[1] + bb.y), p2_pack(v[2] + bb.z, v[3] + bb.w)});
+                        }
+                    }
+                }
+            } else {
+                // ---- output halves.  later blocks: slot S0 + 8 g + kb = Ws[half g] k-block kb (fragments 0..7, B = raw x) and
+                // W1[half g] k-block kb (fragments 8..15, B = hidden); block_0: slot S0 + 4 g + p = W1[half g] k-blocks 2p, 2p + 1
+                constexpr int PER_HALF = FIRST ? 4 : 8;
+                const int g = (s - S0) / PER_HALF, q = (s - S0) % PER_HALF;
+                if (q == 0) {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) { acc1[n][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[n][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                }
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+                    const int kb = FIRST ? 2 * q + part : q;
+                    p2_u32x4 b0v, b1v;
+                    if (!FIRST && part == 0) { b0v = xr[FIRST ? 0 : s % 3][0]; b1v = xr[FIRST ? 0 : s % 3][1]; }
+                    else { b0v = hf[kb][0]; b1v = hf[kb][1]; }
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) {
+                        const uint4 w4 = rp[(part * 8 + n) * 64];
+                        const p2_bf16x8 wa = __builtin_bit_cast(p2_bf16x8, w4);
+                        acc1[n][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(p2_bf16x8, b0v), acc1[n][0], 0, 0, 0);
+                        acc1[n][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(p2_bf16x8, b1v), acc1[n][1], 0, 0, 0);
+                    }
+                }
+                if (q == PER_HALF - 1) {
+                    if (FIRST) {
+                        // folded shortcut (3 -> 256, bias included) on the matrix cores, into the same accumulator
+#pragma unroll
+                        for (int n = 0; n < 8; ++n)
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt)
+                                acc1[n][mt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(p2_s16x4, ssc3f[(8 * g + n) * 64 + lane]), pfr[mt], acc1[n][mt], 0, 0, 0);
+                        if (g == 1 && more) issue_pts(t + 1);                 // (pfr holds this tile's points until make_pfr of the next)
+                    }
+                    // ---- epilogue of half g: bias, bf16 store, column max.  Feature tiles 8g + n = group (2g + n/4), t = n%4:
+                    // lane (r, kq) holds features 64 grp + 16 kq + 4 t + i of point row0 + 16 mt + r -- 16 consecutive per group
+#pragma unroll
+                    for (int gl = 0; gl < 2; ++gl) {
+                        const int grp = 2 * g + gl;
+                        float bv[16], mx[16];
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const float4 b4 = *reinterpret_cast<const float4*>(sb1 + 64 * grp + 16 * kq + 4 * q4);
+                            bv[4 * q4] = b4.x; bv[4 * q4 + 1] = b4.y; bv[4 * q4 + 2] = b4.z; bv[4 * q4 + 3] = b4.w;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) mx[j] = -INFINITY;
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            float v[16];
+#pragma unroll
+                            for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[4 * tq + i] = acc1[4 * gl + tq][mt][i] + bv[4 * tq + i];
+                            if (has_out) {
+                                unsigned w[8];
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) w[e] = p2_pack(v[2 * e], v[2 * e + 1]);
+                                const unsigned vo = (unsigned)(((row0 + r) * P2_H + 64 * grp + 16 * kq) * 2);
+                                __builtin_amdgcn_raw_buffer_store_b128(p2_u32x4{w[0], w[1], w[2], w[3]}, ro, vo, (unsigned)(mt * 16 * P2_H * 2), 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(p2_u32x4{w[4], w[5], w[6], w[7]}, ro, vo + 16u, (unsigned)(mt * 16 * P2_H * 2), 0);
+                            }
+                            if (row0 + mt * 16 + r < rows_valid) {
+#pragma unroll
+                                for (int j = 0; j < 16; ++j) mx[j] = p2_max(mx[j], v[j]);
+                            }
+                        }
+                        // column max over the wave's 32 points: reduce-scatter over the 16 lanes of a DPP row (15 exchanges);
+                        // lane r ends with feature r of the group's 16
+                        auto xch = [](float send, int sel) {
+                            const int iv = __float_as_int(send);
+                            return __int_as_float(sel == 0 ? __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xF, 0xF, true)
+                                                : sel == 1 ? __builtin_amdgcn_update_dpp(0, iv, 0x141, 0xF, 0xF, true)
+                                                : sel == 2 ? __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xF, 0xF, true)
+                                                           : __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xF, 0xF, true));
+                        };
+                        float a8[8], a4[4], a2[2], a1;
+                        const bool b3 = r & 8, b2 = r & 4, b1 = r & 2, b0b = r & 1;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a8[j] = p2_max(b3 ? mx[j + 8] : mx[j], xch(b3 ? mx[j] : mx[j + 8], 0));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a4[j] = p2_max(b2 ? a8[j + 4] : a8[j], xch(b2 ? a8[j] : a8[j + 4], 1));
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) a2[j] = p2_max(b1 ? a4[j + 2] : a4[j], xch(b1 ? a4[j] : a4[j + 2], 2));
+                        a1 = p2_max(b0b ? a2[1] : a2[0], xch(b0b ? a2[0] : a2[1], 3));
+                        if (has_out) a1 = __uint_as_float(p2_pack(a1, 0.f) << 16);   // pool the value the next block reads (rounding is monotone)
+                        smax[wave * P2_H + 64 * grp + 16 * kq + r] = a1;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < P2_H && prev_scene >= 0) {
+        float m = smax[tid];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = p2_max(m, smax[w * P2_H + tid]);
+        p2_atomic_max(a.pool + (size_t)prev_scene * P2_H + tid, p2_max(run_max, m));
+    }
+}
+
+// launch helper used by seeme_pointnet_encode_bf16 (pointnet_bf16.hip)
+int seeme_pn_block2_launch(bool first, const PnBlock2Args& a, int n_cu, hipStream_t st) {
+    const size_t lds = first ? 32768 + 2048 + 8192 + 16384 + 8192 : 32768 + 2048 + 8192;
+    const dim3 grid((unsigned)(a.n_tiles < n_cu ? a.n_tiles : n_cu));
+    if (first) {
+        SEEME_HIP(hipFuncSetAttribute((const void*)k_pn_block2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_pn_block2<true>), grid, dim3(512), lds, st, a);
+    } else {
+        SEEME_HIP(hipFuncSetAttribute((const void*)k_pn_block2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_pn_block2<false>), grid, dim3(512), lds, st, a);
+    }
+    return seeme_check_launch("k_pn_block2");
+}

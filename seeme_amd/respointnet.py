@@ -80,12 +80,59 @@ class ResnetPointnet(nn.Module):
                                 torch.stack([wl[:, 2], bh, bl, zz], -1),
                                 torch.stack([zz, zz, zz, zz], -1)], dim=1)             # [512, kq, 4]
             posf = frag.view(32, 16, 4, 4).permute(0, 2, 1, 3).contiguous()            # [n-tile][kq][q][4]
+            streams, sc3f = self._pack_streams(bf, sc3, perm)
         wb = L.PointnetBf16()
         for i in range(4):
             wb.fc0[i], wb.fc1[i], wb.sc[i] = fc0[i].data_ptr(), fc1[i].data_ptr(), sc[i].data_ptr()
-        wb.sc3, wb.posf = sc3.data_ptr(), posf.data_ptr()
-        self._wcache = (fpnt, w, (posw, fc0, fc1, sc, sc3, posf), wb)
+            wb.stream[i] = streams[i].data_ptr()
+        wb.sc3, wb.posf, wb.sc3f = sc3.data_ptr(), posf.data_ptr(), sc3f.data_ptr()
+        self._wcache = (fpnt, w, (posw, fc0, fc1, sc, sc3, posf, streams, sc3f), wb)
         return w
+
+    @staticmethod
+    def _pack_streams(bf, sc3, perm):
+        """Weight streams of the second-generation block kernel (include/seeme_hip.h: SeemePointnetBf16.stream): per block
+        24 slots x 16 fragments x 64 lanes x 8 bf16 in the order a 256-point tile consumes them, and the folded block_0
+        shortcut as split-bf16 fragments (sc3f)."""
+        dev = sc3.device
+        kq, m, j = torch.meshgrid(torch.arange(4), torch.arange(16), torch.arange(8), indexing="ij")     # lane = 16 kq + m
+        k_nat = (8 * kq + j).reshape(64, 8).to(dev)                    # + 32 kb
+        k_perm = (16 * (j // 4) + 4 * kq + j % 4).reshape(64, 8).to(dev)
+        m_l = m.reshape(64, 8).to(dev)
+        rows_nat = lambda nt: 16 * nt + m_l
+        rows_out = lambda nt: perm.view(16, 16)[nt][m_l]                # row(nt, m) = 64 (nt/4) + 16 (m/4) + 4 (nt%4) + m%4
+
+        def frag(W, rows, kb, permuted):
+            return W[rows, 32 * kb + (k_perm if permuted else k_nat)].to(torch.bfloat16)     # [64, 8]
+
+        def halves(W, permuted):          # slots 4 g + p: fragment 8 kbi + n -> rows row(8 g + n, .), k-block 2 p + kbi
+            return [torch.stack([frag(W, rows_out(8 * g + n), 2 * p + kbi, permuted) for kbi in range(2) for n in range(8)])
+                    for g in range(2) for p in range(4)]
+
+        streams = []
+        for i, b in enumerate(bf):
+            W0, W1, Ws = b.fc_0.weight.float(), b.fc_1.weight.float(), b.shortcut.weight.float()
+            if i == 0:
+                slots = [torch.stack([frag(W0, rows_nat(nt), kb, True) for nt in range(16)]) for kb in range(16)]
+                slots += halves(W1, True)
+            else:
+                slots = [torch.stack([frag(W0, rows_nat(nt), kb, False) for nt in range(16)]) for kb in range(8)]
+                for g in range(2):        # slot 8 + 8 g + kb: shortcut k-block kb (fragments 0..7) | fc_1 k-block kb (fragments 8..15)
+                    slots += [torch.stack([frag(Ws, rows_out(8 * g + n), kb, False) for n in range(8)]
+                                          + [frag(W1, rows_out(8 * g + n), kb, True) for n in range(8)]) for kb in range(8)]
+            assert len(slots) == 24
+            streams.append(torch.stack(slots).contiguous())             # [24, 16, 64, 8] bf16
+        # sc3 [256, 4] = (Ws Wp | Ws bp), rows permuted; k slots as posf: kq 0: whx why whz whx | kq 1: why whz wlx wly | kq 2: wlz bh bl 0
+        sw, sbias = sc3[perm, :3], sc3[perm, 3]
+        wh, bh = sw.to(torch.bfloat16), sbias.to(torch.bfloat16)
+        wl, bl = (sw - wh.float()).to(torch.bfloat16), (sbias - bh.float()).to(torch.bfloat16)
+        zz = torch.zeros_like(bh)
+        fr = torch.stack([torch.stack([wh[:, 0], wh[:, 1], wh[:, 2], wh[:, 0]], -1),
+                          torch.stack([wh[:, 1], wh[:, 2], wl[:, 0], wl[:, 1]], -1),
+                          torch.stack([wl[:, 2], bh, bl, zz], -1),
+                          torch.stack([zz, zz, zz, zz], -1)], dim=1)                  # [256 (permuted rows), kq, 4]
+        sc3f = fr.view(16, 16, 4, 4).permute(0, 2, 1, 3).contiguous()                  # [n-tile][kq][m][4]
+        return streams, sc3f
 
     def forward(self, p: torch.Tensor) -> torch.Tensor:
         """p [B, n_pts, 3] -> [B, out_dim]."""

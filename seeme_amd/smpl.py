@@ -202,6 +202,8 @@ class SMPL(nn.Module):
                 raise ValueError("rotation-matrix pose must hold 24 joints")
         pose = pose.to(torch.float32).contiguous()
         betas = betas.to(torch.float32).contiguous()
+        if transl is not None and transl.shape[0] != M:      # the module's own parameter [batch_size, 3] (smplx broadcasts it)
+            transl = transl.reshape(-1, 3).expand(M, 3)
         tr = None if transl is None else transl.to(torch.float32).reshape(M, 3).contiguous()
         dev = betas.device
         joints = torch.empty(M, 45, 3, device=dev, dtype=torch.float32)
