@@ -1,7 +1,7 @@
 """Debug: which part of the stage-2 training step survives hipGraph capture (each stage in a child process)."""
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-STAGES = ["vae_encode", "forward_nograd", "forward", "fwd_bwd_twin", "fwd_bwd", "fwd_bwd_bucket", "adamw_only", "full"]
+STAGES = ["full", "api_e2_w1", "api_e2_w2", "api_e3_w1", "api_e3_w3", "full_e2_w1", "full_e2_w2"]
 
 
 def child(stage):
@@ -21,9 +21,20 @@ def child(stage):
     model = model.to(dev).train()
     tb = dm.batch(4, idx=3)
     model.configure_optimizers()
-    for _ in range(3):
+    n_eager, n_warm = 3, 2
+    if "_e" in stage:
+        n_eager, n_warm = int(stage.split("_e")[1][0]), int(stage.split("_w")[1][0])
+    for _ in range(n_eager):
         model.optimizer_step(model.training_step(tb))
     torch.cuda.synchronize()
+    if stage.startswith("api"):
+        replay = model.capture_training_step(tb, warmup=n_warm)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            out = replay()
+        torch.cuda.synchronize()
+        print(f"stage {stage}: OK, value {float(out):.6f}", flush=True)
+        return
     losses = model.losses["train"]
     fused = model._fused_adamw
 
@@ -50,12 +61,12 @@ def child(stage):
             return loss.detach()
         model.backward(loss)
         fused.step(device_step=True)
-        return loss.detach()
+        return loss
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        for _ in range(2):
+        for _ in range(n_warm):
             body()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
