@@ -5,7 +5,7 @@
 // the block's three weight matrices from L2 for every 64-point tile -- 384 KiB per 64 points per workgroup, i.e. the
 // vector-memory path of a CU (64 B/clk) had to run flat out for the matrix cores to run flat out, and each ran at half.
 // Here the weights of a block are ONE packed stream of 24 slots x 16 KiB (host-packed in the order of use) that a
-// 512-thread workgroup pulls ONCE per 256-point tile into a two-slot LDS ring (16 B/clk of the vector-memory path),
+// 512-thread workgroup pulls ONCE per 256-point tile into a three-slot LDS ring (16 B/clk of the vector-memory path),
 // and all eight waves read their weight fragments from that ring (ds_read_b128, lane-linear, conflict-free):
 //
 //   wave w owns points [32 w, 32 w + 32) of the tile and ALL 256 features of them, with the weight fragment as the
@@ -41,6 +41,10 @@ typedef __bf16 p2_bf16x2 __attribute__((ext_vector_type(2)));
 #define P2_MT 256                 // points per tile (8 waves x 32)
 #define P2_SLOTS 24               // 16-KiB slots of the weight stream per tile
 #define P2_SLOT_U4 1024           // uint4 per slot
+#define P2_RING 3                 // ring positions: slot s is read during step s (its first fragments already before the barrier that
+                                  // opens the step), slot s + 2 is written during step s, slot s + 3 is in flight from L2
+#define P2_RING_BYTES (P2_RING * 16384)
+#define P2_PRE 4                  // weight fragments read ahead of the MFMAs that consume them
 
 __device__ __forceinline__ float p2_max(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
 __device__ __forceinline__ unsigned p2_pack(float lo, float hi) {
@@ -59,19 +63,19 @@ __device__ __forceinline__ void p2_atomic_max(float* p, float v) {
 template <bool FIRST>
 __global__ __launch_bounds__(512, 2) void k_pn_block2(const PnBlock2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS carve (bytes): ring 2 x 16384 | sb0 1024 | sb1 1024 | smax 8 x 1024 | block_0: sposf 16384 | ssc3f 8192
+    // LDS carve (bytes): ring 3 x 16384 | sb0 1024 | sb1 1024 | smax 8 x 1024 | block_0: sposf 16384 | ssc3f 8192
     uint4* const ring = reinterpret_cast<uint4*>(smem);
-    float* const sb0 = reinterpret_cast<float*>(smem + 32768);
+    float* const sb0 = reinterpret_cast<float*>(smem + P2_RING_BYTES);
     float* const sb1 = sb0 + P2_H;
     float* const smax = sb1 + P2_H;                                   // [8][256]
-    const uint2* const sposf = reinterpret_cast<const uint2*>(smem + 32768 + 2048 + 8192);
+    const uint2* const sposf = reinterpret_cast<const uint2*>(smem + P2_RING_BYTES + 2048 + 8192);
     const uint2* const ssc3f = sposf + 32 * 64;
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 15, kq = lane >> 4;
     const int row0 = wave * 32;
 
     if (FIRST) {
-        uint2* wp = reinterpret_cast<uint2*>(smem + 32768 + 2048 + 8192);
+        uint2* wp = reinterpret_cast<uint2*>(smem + P2_RING_BYTES + 2048 + 8192);
         for (int c = tid; c < 32 * 64; c += 512) wp[c] = a.posf[c];
         for (int c = tid; c < 16 * 64; c += 512) wp[32 * 64 + c] = a.sc3f[c];
         if (tid < P2_H) { sb0[tid] = a.b0[tid]; sb1[tid] = a.b1[tid]; }
@@ -108,9 +112,12 @@ __global__ __launch_bounds__(512, 2) void k_pn_block2(const PnBlock2Args a) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x + ((size_t)sc * a.P + q0) * P2_H), 0, rv * P2_H * 2, 0x00020000);
     };
     const unsigned x_lane = (unsigned)(((row0 + r) * P2_H + 8 * kq) * 2);
+    const unsigned o_lane = (unsigned)(((row0 + r) * P2_H + 16 * kq) * 2);   // output: 16 consecutive features per (group, row tile)
     auto x_load = [&](const __amdgpu_buffer_rsrc_t& rt, int kb, p2_u32x4 (&dst)[2]) {
-        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rt, x_lane + (unsigned)(kb * 64), 0u, 0);
-        dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rt, x_lane + (unsigned)(kb * 64), (unsigned)(16 * P2_H * 2), 0);
+        // ONE lane offset for every k-block and row tile: the rest travels as the scalar offset (per-(kb, mt) lane offsets are
+        // loop invariants the compiler keeps -- and spills -- across the tile loop)
+        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rt, x_lane, (unsigned)(kb * 64), 0);
+        dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rt, x_lane, (unsigned)(kb * 64 + 16 * P2_H * 2), 0);
     };
     auto issue_pts = [&](int tn) {
         const int sc = tn / a.tiles_x, q0 = (tn - sc * a.tiles_x) * P2_MT, rv = min(P2_MT, a.P - q0);
@@ -143,6 +150,12 @@ __global__ __launch_bounds__(512, 2) void k_pn_block2(const PnBlock2Args a) {
     if (FIRST) issue_pts(t0);
     else { x_load(rx, 0, xr[0]); x_load(rx, 1, xr[1]); }
     w_store(0, stg[0]);
+    w_store(1, stg[1]);
+    w_load(2, stg[0]);
+    __syncthreads();
+    uint4 af[P2_PRE];                      // the first fragments of the slot about to be consumed
+#pragma unroll
+    for (int i = 0; i < P2_PRE; ++i) af[i] = rl[i * 64];
 
     for (int t = t0; t < t1; ++t) {
         const int scene = t / a.tiles_x, p0 = (t - scene * a.tiles_x) * P2_MT;
@@ -160,29 +173,20 @@ __global__ __launch_bounds__(512, 2) void k_pn_block2(const PnBlock2Args a) {
         for (int s = 0; s < P2_SLOTS; ++s) {
             // ---- ring turn: slot s was written one step ago; after the barrier it is readable and the other position is free
             __syncthreads();
-            if (s + 2 < P2_SLOTS) w_load(s + 2, stg[s & 1]);
-            else if (more) w_load(s + 2 - P2_SLOTS, stg[s & 1]);
-            if (s + 1 < P2_SLOTS || more) w_store((s + 1) & 1, stg[(s + 1) & 1]);
-            const uint4* const rp = rl + (s & 1) * P2_SLOT_U4;
+            if (s + 3 < P2_SLOTS) w_load(s + 3, stg[(s + 1) & 1]);
+            else if (more) w_load(s + 3 - P2_SLOTS, stg[(s + 1) & 1]);
+            if (s + 2 < P2_SLOTS || more) w_store((s + 2) % P2_RING, stg[s & 1]);
+            const uint4* const rp = rl + (s % P2_RING) * P2_SLOT_U4;
+            const uint4* const rn = rl + ((s + 1) % P2_RING) * P2_SLOT_U4;     // the next slot: complete since the barrier above
             if (!FIRST) {                                      // x k-block of step s + 2 (k-block = step % 8), across the tile boundary
                 if (s + 2 == P2_SLOTS && more) rx = tile_rsrc(t + 1);
                 if (s + 2 < P2_SLOTS || more) x_load(rx, (s + 2) % 8, xr[(s + 2) % 3]);
             }
 
             if (s == 0) {
-#pragma unroll
-                for (int nt = 0; nt < 16; ++nt) { acc0[nt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc0[nt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                // biases + pooled halves of this tile's scene (later blocks), after the barrier that ended the previous tile's reads
-                if (!FIRST && scene != bias_scene) {
-                    if (tid < P2_H) {
-                        sb0[tid] = a.b0[tid] + a.v0[(size_t)scene * P2_H + tid];
-                        sb1[tid] = a.b1[tid] + a.vs[(size_t)scene * P2_H + tid];
-                    }
-                    bias_scene = scene;
-                }
-            }
-            if (s == 2) {
-                // fold the previous tile's column maxima (written before this tile's first barrier) into the running one
+                // (the two rare, branchy pieces of a tile sit here, where only the rings are live: next to the accumulators
+                // they made the register allocator spill accumulators around their branches)
+                // fold the previous tile's column maxima (complete since the barrier above) into the running one
                 if (tid < P2_H && prev_scene >= 0) {
                     float m = smax[tid];
 #pragma unroll
@@ -194,6 +198,17 @@ __global__ __launch_bounds__(512, 2) void k_pn_block2(const PnBlock2Args a) {
                     }
                 }
                 prev_scene = scene;
+                // biases + pooled halves of this tile's scene (later blocks); the previous tile's reads ended before the barrier
+                if (!FIRST && scene != bias_scene) {
+                    if (tid < P2_H) {
+                        sb0[tid] = a.b0[tid] + a.v0[(size_t)scene * P2_H + tid];
+                        sb1[tid] = a.b1[tid] + a.vs[(size_t)scene * P2_H + tid];
+                    }
+                    bias_scene = scene;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < 16; ++nt) { acc0[nt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc0[nt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
 
             constexpr int S0 = FIRST ? 16 : 8;                 // slots of fc_0
@@ -213,10 +228,15 @@ __global__ __launch_bounds__(512, 2) void k_pn_block2(const PnBlock2Args a) {
                 }
 #pragma unroll
                 for (int nt = 0; nt < 16; ++nt) {
-                    const uint4 w4 = rp[nt * 64];
-                    const p2_bf16x8 wa = __builtin_bit_cast(p2_bf16x8, w4);
+                    const p2_bf16x8 wa = __builtin_bit_cast(p2_bf16x8, af[nt % P2_PRE]);
+                    af[nt % P2_PRE] = nt + P2_PRE < 16 ? rp[(nt + P2_PRE) * 64] : rn[(nt + P2_PRE - 16) * 64];
                     acc0[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(p2_bf16x8, b[0]), acc0[nt][0], 0, 0, 0);
                     acc0[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(p2_bf16x8, b[1]), acc0[nt][1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 16; ++nt) {          // pin the interleave: one fragment read, then the two MFMAs of an older one
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
                 if (s == S0 - 1) {
                     // ---- hidden = relu(acc0 + bias) as the B fragments of fc_1 (k order: see the header; W1 is packed to match)
@@ -238,8 +258,13 @@ __global__ __launch_bounds__(512, 2) void k_pn_block2(const PnBlock2Args a) {
                 constexpr int PER_HALF = FIRST ? 4 : 8;
                 const int g = (s - S0) / PER_HALF, q = (s - S0) % PER_HALF;
                 if (q == 0) {
+                    // the accumulator starts at the bias (+ pooled half): tile 8 g + n holds features 64 (2g + n/4) + 16 kq + 4 (n%4) + i
 #pragma unroll
-                    for (int n = 0; n < 8; ++n) { acc1[n][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[n][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    for (int n = 0; n < 8; ++n) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(sb1 + 64 * (2 * g + n / 4) + 16 * kq + 4 * (n % 4));
+                        acc1[n][0] = f32x4{b4.x, b4.y, b4.z, b4.w};
+                        acc1[n][1] = acc1[n][0];
+                    }
                 }
 #pragma unroll
                 for (int part = 0; part < 2; ++part) {
@@ -249,11 +274,17 @@ __global__ __launch_bounds__(512, 2) void k_pn_block2(const PnBlock2Args a) {
                     else { b0v = hf[kb][0]; b1v = hf[kb][1]; }
 #pragma unroll
                     for (int n = 0; n < 8; ++n) {
-                        const uint4 w4 = rp[(part * 8 + n) * 64];
-                        const p2_bf16x8 wa = __builtin_bit_cast(p2_bf16x8, w4);
+                        const int f = part * 8 + n;
+                        const p2_bf16x8 wa = __builtin_bit_cast(p2_bf16x8, af[f % P2_PRE]);
+                        af[f % P2_PRE] = f + P2_PRE < 16 ? rp[(f + P2_PRE) * 64] : rn[(f + P2_PRE - 16) * 64];
                         acc1[n][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(p2_bf16x8, b0v), acc1[n][0], 0, 0, 0);
                         acc1[n][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(p2_bf16x8, b1v), acc1[n][1], 0, 0, 0);
                     }
+                }
+#pragma unroll
+                for (int f = 0; f < 16; ++f) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
                 if (q == PER_HALF - 1) {
                     if (FIRST) {
@@ -270,12 +301,7 @@ __global__ __launch_bounds__(512, 2) void k_pn_block2(const PnBlock2Args a) {
 #pragma unroll
                     for (int gl = 0; gl < 2; ++gl) {
                         const int grp = 2 * g + gl;
-                        float bv[16], mx[16];
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            const float4 b4 = *reinterpret_cast<const float4*>(sb1 + 64 * grp + 16 * kq + 4 * q4);
-                            bv[4 * q4] = b4.x; bv[4 * q4 + 1] = b4.y; bv[4 * q4 + 2] = b4.z; bv[4 * q4 + 3] = b4.w;
-                        }
+                        float mx[16];
 #pragma unroll
                         for (int j = 0; j < 16; ++j) mx[j] = -INFINITY;
 #pragma unroll
@@ -284,14 +310,13 @@ __global__ __launch_bounds__(512, 2) void k_pn_block2(const PnBlock2Args a) {
 #pragma unroll
                             for (int tq = 0; tq < 4; ++tq)
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) v[4 * tq + i] = acc1[4 * gl + tq][mt][i] + bv[4 * tq + i];
+                                for (int i = 0; i < 4; ++i) v[4 * tq + i] = acc1[4 * gl + tq][mt][i];
                             if (has_out) {
                                 unsigned w[8];
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) w[e] = p2_pack(v[2 * e], v[2 * e + 1]);
-                                const unsigned vo = (unsigned)(((row0 + r) * P2_H + 64 * grp + 16 * kq) * 2);
-                                __builtin_amdgcn_raw_buffer_store_b128(p2_u32x4{w[0], w[1], w[2], w[3]}, ro, vo, (unsigned)(mt * 16 * P2_H * 2), 0);
-                                __builtin_amdgcn_raw_buffer_store_b128(p2_u32x4{w[4], w[5], w[6], w[7]}, ro, vo + 16u, (unsigned)(mt * 16 * P2_H * 2), 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(p2_u32x4{w[0], w[1], w[2], w[3]}, ro, o_lane, (unsigned)(mt * 16 * P2_H * 2 + grp * 128), 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(p2_u32x4{w[4], w[5], w[6], w[7]}, ro, o_lane, (unsigned)(mt * 16 * P2_H * 2 + grp * 128 + 16), 0);
                             }
                             if (row0 + mt * 16 + r < rows_valid) {
 #pragma unroll
@@ -318,6 +343,7 @@ __global__ __launch_bounds__(512, 2) void k_pn_block2(const PnBlock2Args a) {
                         a1 = p2_max(b0b ? a2[1] : a2[0], xch(b0b ? a2[0] : a2[1], 3));
                         if (has_out) a1 = __uint_as_float(p2_pack(a1, 0.f) << 16);   // pool the value the next block reads (rounding is monotone)
                         smax[wave * P2_H + 64 * grp + 16 * kq + r] = a1;
+                        __builtin_amdgcn_sched_barrier(0);       // one group at a time: the epilogue's temporaries are not doubled
                     }
                 }
             }
@@ -334,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void k_pn_block2(const PnBlock2Args a) {
 
 // launch helper used by seeme_pointnet_encode_bf16 (pointnet_bf16.hip)
 int seeme_pn_block2_launch(bool first, const PnBlock2Args& a, int n_cu, hipStream_t st) {
-    const size_t lds = first ? 32768 + 2048 + 8192 + 16384 + 8192 : 32768 + 2048 + 8192;
+    const size_t lds = P2_RING_BYTES + 2048 + 8192 + (first ? 16384 + 8192 : 0);
     const dim3 grid((unsigned)(a.n_tiles < n_cu ? a.n_tiles : n_cu));
     if (first) {
         SEEME_HIP(hipFuncSetAttribute((const void*)k_pn_block2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
