@@ -290,18 +290,16 @@ typedef struct {
                                  * kq 0: whx why whz whx | kq 1: why whz wlx wly | kq 2: wlz bh bl 0 | kq 3: 0 */
     const float* sc3;           /* block_0.shortcut folded through fc_pos_0 (both linear, no bias: respointnet.py:35,84,93):
                                  * [256][4] fp32 = ( Ws Wp | Ws bp ) */
-    /* Second-generation block kernel (csrc/pointnet_v2.hip; used when stream[0] != NULL): per block ONE weight stream of
-     * 24 slots x 16 fragments x 64 lanes x 8 bf16, in the order a 256-point tile consumes it.  Fragment (rows R(.), k-block
-     * kb, k order natural or permuted): lane 16*kq + m, element j = W[R(m)][k(kb, kq, j)] with natural k = 32 kb + 8 kq + j
-     * and permuted k = 32 kb + 16 (j/4) + 4 kq + j%4 (the order in which an accumulator tile pair becomes the next B operand).
-     *   block_0:   slots 0..15 fc_0 k-block = slot, fragment nt: rows 16 nt + m, permuted k (its input is generated in
-     *              accumulators); slots 16 + 4 g + p: fc_1 half g, fragment 8 kbi + n: rows row(8 g + n, m) as above,
-     *              k-block 2 p + kbi, permuted k.
-     *   block_1-3: slots 0..7 fc_0[:, :256] k-block = slot, fragment nt: rows 16 nt + m, natural k; slot 8 + 8 g + kb:
-     *              fragments 0..7 shortcut[:, :256] rows row(8 g + n, m), k-block kb, natural k; fragments 8..15 fc_1 rows
-     *              row(8 g + n, m), k-block kb, permuted k. */
+    /* Second-generation block kernels (csrc/pointnet_v2.hip; used when stream[0] != NULL): per block ONE weight stream of
+     * 24 slots x 16 fragments x 64 lanes x 8 bf16, in the order a 256-point tile consumes it.  Fragment (feature tile nt,
+     * k-block kb): lane 16*kq + m, element j = W[16 nt + m][32 kb + 16 (j/4) + 4 kq + j%4] -- the k order in which an
+     * accumulator tile pair is the next B operand; the activations between blocks are stored in that order too.
+     *   block_0:   slots 0..15 fc_0 k-block = slot, fragment nt; slot 16 + 4 g + p: fc_1 tiles 8 g + n, k-blocks 2 p + kbi
+     *              at fragment 8 kbi + n.
+     *   block_1-3: slots 0..7 fc_0[:, :256] k-block = slot, fragment nt; slot 8 + 8 g + kb: fragments 0..7 shortcut[:, :256]
+     *              tiles 8 g + n, fragments 8..15 fc_1 tiles 8 g + n, both k-block kb. */
     const uint16_t* stream[4];
-    const uint16_t* sc3f;       /* sc3 as split-bf16 fragments like posf, rows permuted by row(.): [16 n-tiles][64 lanes][4] */
+    const uint16_t* sc3f;       /* sc3 as split-bf16 fragments like posf: [16 n-tiles][64 lanes][4] */
 } SeemePointnetBf16;
 size_t seeme_pointnet_bf16_workspace_bytes(int B, int P);
 int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const SeemePointnetBf16* wb, const float* points,

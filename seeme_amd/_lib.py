@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libseeme_hip.so")
+# SEEME_HIP_LIB: another build of the same library (A/B timing of kernel variants, debug builds with cycle stamps)
+LIB_PATH = os.environ.get("SEEME_HIP_LIB") or os.path.join(_HERE, "libseeme_hip.so")
 
 NLAYERS = 5
 TROW = 7680

@@ -448,7 +448,7 @@ __global__ void k_fill(float* p, float v, size_t n) {
 }
 
 extern "C" size_t seeme_pointnet_bf16_workspace_bytes(int B, int P) {
-    const size_t M = (size_t)B * P;
+    const size_t M = (size_t)B * ((P + 15) / 16 * 16);        // rows per scene padded to the 16-point tiles of the fragment-order layout
     return M * PN_H * 2 * sizeof(unsigned short) + (size_t)B * PN_H * 6 * sizeof(float) + 256;
 }
 
@@ -490,7 +490,7 @@ extern "C" int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const S
     hipStream_t st = (hipStream_t)stream;
     if (B <= 0 || P <= 0 || B > 65535) return seeme_fail("pointnet_bf16: bad sizes");
     if (ws_bytes < seeme_pointnet_bf16_workspace_bytes(B, P)) return seeme_fail("pointnet_bf16: workspace too small");
-    const size_t M = (size_t)B * P;
+    const size_t M = (size_t)B * ((P + 15) / 16 * 16);
     unsigned short* xa = (unsigned short*)workspace;
     unsigned short* xb = xa + M * PN_H;
     float* pools = (float*)(xb + M * PN_H);        // 4 x [B,256]
@@ -518,43 +518,14 @@ extern "C" int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const S
     SEEME_HIP(hipFuncSetAttribute((const void*)k_pn_block<false, MH_NEXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_next));
     unsigned short* cur = xa;
     unsigned short* nxt = xb;
-    static int use_v2 = -1;
-    if (use_v2 < 0) { const char* e = getenv("SEEME_PN_V2"); use_v2 = (e == nullptr || e[0] != '0') ? 1 : 0; }
-    const bool v2 = use_v2 && wb->stream[0] != nullptr && wb->sc3f != nullptr;
-    for (int i = 0; v2 && i < 4; ++i) {
-        PnBlock2Args a{};
-        a.P = P; a.tiles_x = (P + 255) / 256; a.n_tiles = a.tiles_x * B;
-        a.stream = (const uint4*)wb->stream[i]; a.b0 = w->fc0_b[i]; a.b1 = w->fc1_b[i];
-        a.pool = pools + (size_t)i * B * PN_H;
-        a.out = (i < 3) ? nxt : nullptr;
-        if (i == 0) {
-            a.points = points; a.posf = (const uint2*)wb->posf; a.sc3f = (const uint2*)wb->sc3f;
-        } else {
-            const float* pool_prev = pools + (size_t)(i - 1) * B * PN_H;
-            PnRowsArgs ra{};
-            ra.pool = pool_prev; ra.w[0] = w->fc0_w[i]; ra.w[1] = w->sc_w[i]; ra.y[0] = v0; ra.y[1] = vs; ra.ldy = PN_H;
-            ra.ldw = 512; ra.col0 = PN_H; ra.relu[0] = 1; ra.relu[1] = 0;
-            hipLaunchKernelGGL(k_pn_rows, dim3((unsigned)B, 4), dim3(512), 0, st, ra);
-            if ((rc = seeme_check_launch("k_pn_rows"))) return rc;
-            a.x = cur; a.v0 = v0; a.vs = vs;
-        }
-        if ((rc = seeme_pn_block2_launch(i == 0, a, n_cu, st))) return rc;
-        if (i > 0) { unsigned short* t = cur; cur = nxt; nxt = t; } else { cur = nxt; nxt = xa; }
-    }
-    for (int i = 0; !v2 && i < 4; ++i) {
-        PnBlockArgs a{};
-        const int mt = 64 * (i == 0 ? MH_FIRST : MH_NEXT), per_cu = 2 / (i == 0 ? MH_FIRST : MH_NEXT);
-        a.P = P; a.tiles_x = (P + mt - 1) / mt; a.n_tiles = a.tiles_x * B;
-        const dim3 grid((unsigned)(a.n_tiles < n_cu * per_cu ? a.n_tiles : n_cu * per_cu));
-        a.w0 = (const uint4*)wb->fc0[i]; a.b0 = w->fc0_b[i];
-        a.w1 = (const uint4*)wb->fc1[i]; a.b1 = w->fc1_b[i];
-        a.ws = (const uint4*)wb->sc[i];
-        a.pool = pools + (size_t)i * B * PN_H;
-        a.out = (i < 3) ? nxt : nullptr;            // the last block only feeds the final pool
-        if (i == 0) {
-            a.points = points; a.posf = (const uint2*)wb->posf; a.sc3 = wb->sc3;
-            hipLaunchKernelGGL((k_pn_block<true, MH_FIRST>), grid, dim3(256 * MH_FIRST), lds_first, st, a);
-        } else {
+    // SEEME_PN_V2: unset / "1" = second-generation block kernels (pointnet_v2.hip), "0" = first generation.  The two keep
+    // the activations between blocks in different layouts (fragment order / row-major), so it is all blocks or none.
+    static int v2_mask = -1;
+    if (v2_mask < 0) { const char* e = getenv("SEEME_PN_V2"); v2_mask = (e == nullptr || e[0] != '0') ? 0xF : 0; }
+    const bool v2_ok = wb->stream[0] != nullptr && wb->sc3f != nullptr;
+    for (int i = 0; i < 4; ++i) {
+        const bool v2 = v2_ok && ((v2_mask >> i) & 1);
+        if (i > 0) {
             const float* pool_prev = pools + (size_t)(i - 1) * B * PN_H;
             // pooled halves in fp32: v0 = W0[:,256:] relu(pool), vs = Ws[:,256:] pool
             PnRowsArgs ra{};
@@ -562,10 +533,36 @@ extern "C" int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const S
             ra.ldw = 512; ra.col0 = PN_H; ra.relu[0] = 1; ra.relu[1] = 0;
             hipLaunchKernelGGL(k_pn_rows, dim3((unsigned)B, 4), dim3(512), 0, st, ra);
             if ((rc = seeme_check_launch("k_pn_rows"))) return rc;
-            a.x = cur; a.v0 = v0; a.vs = vs;
-            hipLaunchKernelGGL((k_pn_block<false, MH_NEXT>), grid, dim3(256 * MH_NEXT), lds_next, st, a);
         }
-        if ((rc = seeme_check_launch("k_pn_block"))) return rc;
+        if (v2) {
+            PnBlock2Args a{};
+            const int tp = seeme_pn_block2_tile_points();
+            a.P = P; a.Ppad = (P + 15) / 16 * 16; a.tiles_x = (P + tp - 1) / tp; a.n_tiles = a.tiles_x * B;
+            a.stream = (const uint4*)wb->stream[i]; a.b0 = w->fc0_b[i]; a.b1 = w->fc1_b[i];
+            a.pool = pools + (size_t)i * B * PN_H;
+            a.out = (i < 3) ? nxt : nullptr;
+            if (i == 0) { a.points = points; a.posf = (const uint2*)wb->posf; a.sc3f = (const uint2*)wb->sc3f; }
+            else { a.x = cur; a.v0 = v0; a.vs = vs; }
+            if ((rc = seeme_pn_block2_launch(i == 0, a, n_cu, st))) return rc;
+        } else {
+            PnBlockArgs a{};
+            const int mt = 64 * (i == 0 ? MH_FIRST : MH_NEXT), per_cu = 2 / (i == 0 ? MH_FIRST : MH_NEXT);
+            a.P = P; a.tiles_x = (P + mt - 1) / mt; a.n_tiles = a.tiles_x * B;
+            const dim3 grid((unsigned)(a.n_tiles < n_cu * per_cu ? a.n_tiles : n_cu * per_cu));
+            a.w0 = (const uint4*)wb->fc0[i]; a.b0 = w->fc0_b[i];
+            a.w1 = (const uint4*)wb->fc1[i]; a.b1 = w->fc1_b[i];
+            a.ws = (const uint4*)wb->sc[i];
+            a.pool = pools + (size_t)i * B * PN_H;
+            a.out = (i < 3) ? nxt : nullptr;            // the last block only feeds the final pool
+            if (i == 0) {
+                a.points = points; a.posf = (const uint2*)wb->posf; a.sc3 = wb->sc3;
+                hipLaunchKernelGGL((k_pn_block<true, MH_FIRST>), grid, dim3(256 * MH_FIRST), lds_first, st, a);
+            } else {
+                a.x = cur; a.v0 = v0; a.vs = vs;
+                hipLaunchKernelGGL((k_pn_block<false, MH_NEXT>), grid, dim3(256 * MH_NEXT), lds_next, st, a);
+            }
+            if ((rc = seeme_check_launch("k_pn_block"))) return rc;
+        }
         if (i > 0) { unsigned short* t = cur; cur = nxt; nxt = t; } else { cur = nxt; nxt = xa; }
     }
     // fc_c(relu(pool of block_3))

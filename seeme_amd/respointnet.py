@@ -96,41 +96,38 @@ class ResnetPointnet(nn.Module):
         shortcut as split-bf16 fragments (sc3f)."""
         dev = sc3.device
         kq, m, j = torch.meshgrid(torch.arange(4), torch.arange(16), torch.arange(8), indexing="ij")     # lane = 16 kq + m
-        k_nat = (8 * kq + j).reshape(64, 8).to(dev)                    # + 32 kb
+        # every B operand of these kernels is built from an accumulator tile pair (generated input, hidden tile, stored
+        # activations): element j of lane (kq, .) of k-block kb is feature 32 kb + 16 (j/4) + 4 kq + j%4
         k_perm = (16 * (j // 4) + 4 * kq + j % 4).reshape(64, 8).to(dev)
         m_l = m.reshape(64, 8).to(dev)
         rows_nat = lambda nt: 16 * nt + m_l
-        rows_out = lambda nt: perm.view(16, 16)[nt][m_l]                # row(nt, m) = 64 (nt/4) + 16 (m/4) + 4 (nt%4) + m%4
 
-        def frag(W, rows, kb, permuted):
-            return W[rows, 32 * kb + (k_perm if permuted else k_nat)].to(torch.bfloat16)     # [64, 8]
-
-        def halves(W, permuted):          # slots 4 g + p: fragment 8 kbi + n -> rows row(8 g + n, .), k-block 2 p + kbi
-            return [torch.stack([frag(W, rows_out(8 * g + n), 2 * p + kbi, permuted) for kbi in range(2) for n in range(8)])
-                    for g in range(2) for p in range(4)]
+        def frag(W, nt, kb):                # feature tile nt (rows 16 nt + m), k-block kb in the permuted k order
+            return W[rows_nat(nt), 32 * kb + k_perm].to(torch.bfloat16)     # [64, 8]
 
         streams = []
         for i, b in enumerate(bf):
             W0, W1, Ws = b.fc_0.weight.float(), b.fc_1.weight.float(), b.shortcut.weight.float()
-            if i == 0:
-                slots = [torch.stack([frag(W0, rows_nat(nt), kb, True) for nt in range(16)]) for kb in range(16)]
-                slots += halves(W1, True)
-            else:
-                slots = [torch.stack([frag(W0, rows_nat(nt), kb, False) for nt in range(16)]) for kb in range(8)]
-                for g in range(2):        # slot 8 + 8 g + kb: shortcut k-block kb (fragments 0..7) | fc_1 k-block kb (fragments 8..15)
-                    slots += [torch.stack([frag(Ws, rows_out(8 * g + n), kb, False) for n in range(8)]
-                                          + [frag(W1, rows_out(8 * g + n), kb, True) for n in range(8)]) for kb in range(8)]
+            if i == 0:      # slots 0..15: fc_0 k-block = slot; slot 16 + 4 g + p: fc_1 half g, fragment 8 kbi + n = tile 8 g + n, k-block 2 p + kbi
+                slots = [torch.stack([frag(W0, nt, kb) for nt in range(16)]) for kb in range(16)]
+                slots += [torch.stack([frag(W1, 8 * g + n, 2 * p + kbi) for kbi in range(2) for n in range(8)])
+                          for g in range(2) for p in range(4)]
+            else:           # slots 0..7: fc_0[:, :256]; slot 8 + 8 g + kb: shortcut[:, :256] tiles 8 g + n (fragments 0..7) | fc_1 (8..15)
+                slots = [torch.stack([frag(W0, nt, kb) for nt in range(16)]) for kb in range(8)]
+                for g in range(2):
+                    slots += [torch.stack([frag(Ws, 8 * g + n, kb) for n in range(8)] + [frag(W1, 8 * g + n, kb) for n in range(8)])
+                              for kb in range(8)]
             assert len(slots) == 24
             streams.append(torch.stack(slots).contiguous())             # [24, 16, 64, 8] bf16
-        # sc3 [256, 4] = (Ws Wp | Ws bp), rows permuted; k slots as posf: kq 0: whx why whz whx | kq 1: why whz wlx wly | kq 2: wlz bh bl 0
-        sw, sbias = sc3[perm, :3], sc3[perm, 3]
+        # sc3 [256, 4] = (Ws Wp | Ws bp); k slots as posf: kq 0: whx why whz whx | kq 1: why whz wlx wly | kq 2: wlz bh bl 0
+        sw, sbias = sc3[:, :3], sc3[:, 3]
         wh, bh = sw.to(torch.bfloat16), sbias.to(torch.bfloat16)
         wl, bl = (sw - wh.float()).to(torch.bfloat16), (sbias - bh.float()).to(torch.bfloat16)
         zz = torch.zeros_like(bh)
         fr = torch.stack([torch.stack([wh[:, 0], wh[:, 1], wh[:, 2], wh[:, 0]], -1),
                           torch.stack([wh[:, 1], wh[:, 2], wl[:, 0], wl[:, 1]], -1),
                           torch.stack([wl[:, 2], bh, bl, zz], -1),
-                          torch.stack([zz, zz, zz, zz], -1)], dim=1)                  # [256 (permuted rows), kq, 4]
+                          torch.stack([zz, zz, zz, zz], -1)], dim=1)                  # [256, kq, 4]
         sc3f = fr.view(16, 16, 4, 4).permute(0, 2, 1, 3).contiguous()                  # [n-tile][kq][m][4]
         return streams, sc3f
 

@@ -265,22 +265,21 @@ def test_smpl_pkl_loader_is_code_free(tmp_path):
 
 # ----------------------------------------------------------------------------- PointNet v2: packing of the weight streams
 def test_pointnet_v2_stream_packing_emulated():
-    """The second-generation PointNet block kernel (csrc/pointnet_v2.hip) consumes host-packed weight streams whose k order
-    and row order encode the kernel's register layouts (accumulator tile pair -> next B operand; 16 consecutive features
-    per lane).  This emulates the kernel's dataflow on the CPU -- MFMA semantics on the packed fragments, slot by slot,
-    bf16 rounding where the kernel rounds -- and compares with the oracle's PointNet: a wrong permutation is an O(1) error."""
+    """The second-generation PointNet block kernels (csrc/pointnet_v2.hip) consume host-packed weight streams whose k order
+    encodes the kernel's register layouts (accumulator tile pair -> next B operand), and keep the activations between
+    blocks in that fragment order.  This emulates the kernel's dataflow on the CPU -- MFMA semantics on the packed
+    fragments, slot by slot, bf16 rounding where the kernel rounds, the activation layout of the stores / loads -- and
+    compares with the oracle's PointNet: a wrong permutation is an O(1) error."""
     from oracle import mld_oracle as O
     from seeme_amd import shapes
     from seeme_amd.respointnet import ResnetPointnet
     from seeme_amd.weights_recipe import load_recipe_, recipe_state_dict
     pn = load_recipe_(ResnetPointnet(512, 256)).eval()
     bf = [getattr(pn, f"block_{i}") for i in range(4)]
-    tt, qq = torch.meshgrid(torch.arange(16), torch.arange(16), indexing="ij")
-    perm = (64 * (tt // 4) + 16 * (qq // 4) + 4 * (tt % 4) + qq % 4).reshape(-1)
     ws0 = bf[0].shortcut.weight.double()
     sc3 = torch.cat([ws0 @ pn.fc_pos_0.weight.double(), (ws0 @ pn.fc_pos_0.bias.double())[:, None]], dim=1).float()
     with torch.no_grad():
-        streams, sc3f = pn._pack_streams(bf, sc3, perm)
+        streams, sc3f = pn._pack_streams(bf, sc3, None)
     assert all(s.shape == (24, 16, 64, 8) for s in streams) and sc3f.shape == (16, 4, 16, 4)
     bf16 = lambda t: t.to(torch.bfloat16).float()
 
@@ -289,50 +288,46 @@ def test_pointnet_v2_stream_packing_emulated():
 
     rng = np.random.default_rng(11)
     P = 40                                        # one scene, 40 points = 3 point tiles (the last one ragged)
+    NT = (P + 15) // 16
     pts = torch.from_numpy(rng.uniform(-3, 3, (P, 3)).astype(np.float32))
     kq, r = torch.arange(64) // 16, torch.arange(64) % 16
+    jj = torch.arange(8)[None]
     pad = lambda x, n: torch.cat([x, torch.zeros(n - x.shape[0], *x.shape[1:])])
 
-    def run_block(i, x, v0, vs):
-        """x: block_0 -> x512 = relu(fc_pos_0(p)) rounded to bf16 [P,512]; later -> bf16 activations [P,256]."""
+    def acc_pair_to_frag(acc, kb):                # accumulator tiles (2 kb, 2 kb + 1) [tile][row m][col r] -> B fragment [64 lanes, 8]
+        return acc[2 * kb + jj // 4, 4 * kq[:, None] + jj % 4, r[:, None]]
+
+    def run_block(i, xin, v0, vs):
+        """xin: block_0 -> points [P,3]; later -> activations in fragment order [NT][8 kb][64 lanes][8] (bf16 values).
+        Returns (activations in fragment order, per-feature max over the valid points)."""
         b0 = bf[i].fc_0.bias.detach() + (v0 if v0 is not None else 0)
         b1 = bf[i].fc_1.bias.detach() + (vs if vs is not None else 0)
         st = streams[i].float()
-        out = torch.zeros(P, 256)
+        out = torch.zeros(NT, 8, 64, 8)
+        pool = torch.full((256,), -float("inf"))
         nk0 = 16 if i == 0 else 8
-        for p0 in range(0, P, 16):                # one point tile (mt) at a time
-            xt = pad(x[p0:p0 + 16], 16)           # [16 points, K]
-            acc0 = torch.zeros(16, 16, 16)        # [nt][row m][col r]
+        m_idx = torch.arange(16)
+        for pt in range(NT):                      # one 16-point tile (mt) at a time
+            p0 = pt * 16
+            acc0 = (b0.view(16, 16)[:, :, None]).expand(16, 16, 16).clone()          # accumulator starts at the bias: [nt][row m][col r]
+            if i == 0:
+                x512 = bf16(torch.relu(pad(pts[p0:p0 + 16], 16) @ pn.fc_pos_0.weight.T + pn.fc_pos_0.bias)).T      # [feature][point]
             for s in range(nk0):
-                if i == 0:                        # generated input: B element j of lane (r, kq) = feature 32 s + 16 (j/4) + 4 kq + j%4
-                    col = 32 * s + 16 * (torch.arange(8)[None] // 4) + 4 * kq[:, None] + torch.arange(8)[None] % 4
+                if i == 0:                        # generated input: small-MFMA tiles (2 s, 2 s + 1) -> B fragment
+                    Bf = acc_pair_to_frag(x512.view(32, 16, 16), s)
                 else:
-                    col = 32 * s + 8 * kq[:, None] + torch.arange(8)[None]
-                Bf = torch.relu(xt[r[:, None], col])
+                    Bf = torch.relu(xin[pt, s])
                 for nt in range(16):
                     acc0[nt] += mfma(st[s, nt], Bf)
-            # hidden as B fragments: element j of lane (r, kq) = relu(acc0[2 kb + j/4][row 4 kq + j%4][col r] + bias)
-            hf = []
-            for kb in range(8):
-                j = torch.arange(8)[None]
-                nt_ = 2 * kb + j // 4
-                row = 4 * kq[:, None] + j % 4
-                val = acc0[nt_, row, r[:, None]] + b0[16 * nt_ + row]
-                hf.append(bf16(torch.relu(val)))
+            hf = [bf16(torch.relu(acc_pair_to_frag(acc0, kb))) for kb in range(8)]
             for g in range(2):
-                acc1 = torch.zeros(8, 16, 16)
+                acc1 = (b1.view(16, 16)[8 * g:8 * g + 8, :, None]).expand(8, 16, 16).clone()
                 base = nk0 + (4 if i == 0 else 8) * g
                 if i == 0:                        # slot base + p: fc_1 k-blocks 2p, 2p + 1 (fragments 8 kbi + n)
                     for p in range(4):
                         for kbi in range(2):
                             for n in range(8):
                                 acc1[n] += mfma(st[base + p, kbi * 8 + n], hf[2 * p + kbi])
-                else:                             # slot base + kb: shortcut k-block kb (fragments 0..7, raw x) | fc_1 k-block kb (8..15, hidden)
-                    for kb in range(8):
-                        Bx = xt[r[:, None], 32 * kb + 8 * kq[:, None] + torch.arange(8)[None]]
-                        for n in range(8):
-                            acc1[n] += mfma(st[base + kb, n], Bx) + mfma(st[base + kb, 8 + n], hf[kb])
-                if i == 0:                        # folded shortcut through the split-bf16 fragments (rows permuted)
                     fr = sc3f.float().permute(0, 2, 1, 3)             # [n-tile][m][kq][4]
                     px, py, pz = (pad(pts[p0:p0 + 16], 16)[:, c] for c in range(3))
                     h = lambda v: bf16(v)
@@ -342,21 +337,23 @@ def test_pointnet_v2_stream_packing_emulated():
                                           torch.stack([h(pz), one, one, 0 * one], -1), torch.zeros(16, 4)], dim=1)       # [point][kq][4]
                     for n in range(8):
                         acc1[n] += torch.einsum("mqj,rqj->mr", fr[8 * g + n], kslots)
-                for n in range(8):                # rows of tile 8 g + n are features perm[16 (8 g + n) + m]
-                    feats = perm[16 * (8 * g + n) + torch.arange(16)]
-                    out[p0:p0 + 16, feats] = (acc1[n] + b1[feats][:, None]).T[: min(16, P - p0)] if P - p0 < 16 else (acc1[n] + b1[feats][:, None]).T
-        return out
+                else:                             # slot base + kb: shortcut k-block kb (fragments 0..7, raw x) | fc_1 k-block kb (8..15, hidden)
+                    for kb in range(8):
+                        for n in range(8):
+                            acc1[n] += mfma(st[base + kb, n], xin[pt, kb]) + mfma(st[base + kb, 8 + n], hf[kb])
+                for kl in range(4):               # the stored fragment of k-block 4 g + kl = tiles (2 kl, 2 kl + 1) of this half
+                    out[pt, 4 * g + kl] = bf16(acc_pair_to_frag(acc1, kl))
+                valid = min(16, P - p0)
+                mx = bf16(acc1[:, :, :valid]).max(dim=2).values                      # [tile n][row m] -> feature 16 (8 g + n) + m
+                pool[128 * g:128 * g + 128] = torch.maximum(pool[128 * g:128 * g + 128], mx.reshape(-1))
+        return out, pool
 
     with torch.no_grad():
-        x512 = bf16(torch.relu(pts @ pn.fc_pos_0.weight.T + pn.fc_pos_0.bias))
-        net = run_block(0, x512, None, None)
+        act, pooled = run_block(0, pts, None, None)
         for i in (1, 2, 3):
-            pooled = bf16(net).max(0).values if True else None
-            xin = bf16(net)
             W0, Ws = bf[i].fc_0.weight.detach(), bf[i].shortcut.weight.detach()
-            v0 = W0[:, 256:] @ torch.relu(pooled)
-            vs = Ws[:, 256:] @ pooled
-            net = run_block(i, xin, v0, vs)
-        got = (pn.fc_c.weight @ torch.relu(net.max(0).values) + pn.fc_c.bias).numpy()
+            act, pooled_new = run_block(i, act, W0[:, 256:] @ torch.relu(pooled), Ws[:, 256:] @ pooled)
+            pooled = pooled_new
+        got = (pn.fc_c.weight @ torch.relu(pooled) + pn.fc_c.bias).numpy()
     want = O.pointnet_forward(recipe_state_dict(shapes.pointnet_shapes()), pts.numpy()[None])[0]
     assert rel_err(got, want) < 3e-2, rel_err(got, want)
