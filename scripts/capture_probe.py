@@ -1,7 +1,7 @@
 """Debug: which part of the stage-2 training step survives hipGraph capture (each stage in a child process)."""
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-STAGES = ["full", "api_e2_w1", "api_e2_w2", "api_e3_w1", "api_e3_w3", "full_e2_w1", "full_e2_w2"]
+STAGES = ["api_e2_w1", "seed_api_e2_w1", "pts_api_e2_w1", "seedpts_api_e2_w1"]
 
 
 def child(stage):
@@ -15,7 +15,33 @@ def child(stage):
     cfg = parse_config(os.path.join(repo, "configs", "config_mld_egobody.yaml"))
     if stage == "fwd_bwd_twin":
         cfg.TRAIN.HIP_BACKWARD = False
-    dm = SyntheticEgoDataModule(nfeats=75, T=16, device=dev)
+    n_points = 2048
+    if stage.startswith("seed"):
+        torch.manual_seed(7)
+        stage = stage.split("_", 1)[1] if not stage.startswith("seedpts") else "pts_" + stage.split("_", 1)[1]
+    if stage.startswith("pts"):
+        n_points = 384
+        stage = stage.split("_", 1)[1]
+    dm = SyntheticEgoDataModule(nfeats=75, T=16, n_points=n_points, device=dev, pose_dim=72)
+    if stage.startswith("prev"):           # what an earlier test of the same process leaves behind
+        import gc
+        kind = stage.split("_")[0]
+        stage = stage.split("_", 1)[1]
+        prev = MLD(cfg, dm, smpl_model=SMPL.synthetic(1234))
+        load_recipe_(prev.vae), load_recipe_(prev.denoiser)
+        prev = prev.to(dev).train()
+        if kind == "prevrot":
+            prev.eval()
+            prev.ego_eval(dm.batch(2, idx=6, lengths=[16, 13]))
+        else:
+            prev.configure_optimizers()
+            for _ in range(3):
+                prev.optimizer_step(prev.training_step(dm.batch(4, idx=3)))
+        torch.cuda.synchronize()
+        if kind in ("prevdel", "prevgc", "prevrot"):
+            del prev
+        if kind == "prevgc":
+            gc.collect(); torch.cuda.synchronize()
     model = MLD(cfg, dm, smpl_model=SMPL.synthetic(1234))
     load_recipe_(model.vae), load_recipe_(model.denoiser)
     model = model.to(dev).train()

@@ -741,9 +741,14 @@ class MLD(nn.Module):
                 p.grad = None
             loss.backward()
             self._used_params = [p for p in self.trainable_parameters() if p.grad is not None]
-            return None
-        b.prepare()
-        loss.backward()
+        else:
+            b.prepare()
+            loss.backward()
+        # the caller usually keeps `loss` (logging): cut it loose from the autograd graph, or the graph's AccumulateGrad nodes --
+        # created on THIS stream -- stay alive and are reused by a later backward on another stream (a hipGraph capture runs on
+        # a side stream: the engine then synchronises with the non-capturing stream and the capture dies in hipStreamEndCapture)
+        if loss.grad_fn is not None and not torch.cuda.is_current_stream_capturing():
+            loss.detach_()
         return b
 
     def optimizer_step(self, loss, events=None):
