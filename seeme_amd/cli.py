@@ -10,8 +10,8 @@ to ``metrics_<time>.json`` (test.py:136-152).
 
 The argument surface is the reference's (mld/config.py:35-65: --cfg --cfg_assets --batch_size --device
 --nodebug --dir) plus loop bounds for the synthetic data module: the EgoBody / GIMO datasets are
-licence-gated and their loaders are outside this build, so batches come from
-``SyntheticEgoDataModule`` unless a data module with the same ``batch()`` / ``renorm()`` surface is passed in.
+licence-gated: ``--data_root`` points ``seeme_amd.data.EgoDataModule`` at a directory in the reference's on-disk layout
+(split resident in HBM); without it batches come from ``SyntheticEgoDataModule``.
 """
 from __future__ import annotations
 
@@ -45,6 +45,10 @@ def build_parser(phase: str) -> argparse.ArgumentParser:
     s.add_argument("--epochs", type=int, default=None, help="override TRAIN.END_EPOCH")
     s.add_argument("--iters_per_epoch", type=int, default=8, help="batches per epoch and rank")
     s.add_argument("--test_batches", type=int, default=4, help="batches per replication and rank")
+    s.add_argument("--data_root", type=str, default=None,
+                   help="directory in the reference's EgoBody / GIMO on-disk layout (seeme_amd/data.py); default: synthetic batches")
+    s.add_argument("--scene_root", type=str, default=None, help="scene tables of --data_root (default: the same directory)")
+    s.add_argument("--storage", type=str, default="device", choices=["device", "pinned"], help="where --data_root's splits live")
     s.add_argument("--scene_points", type=int, default=20000)
     s.add_argument("--frames", type=int, default=196)
     s.add_argument("--folder", type=str, default=None, help="override FOLDER (experiment root)")
@@ -126,6 +130,11 @@ def build(cfg, dev, args, datamodule=None, smpl_model=None):
     from .mld import MLD, SyntheticEgoDataModule
     from .smpl import SMPL
     nfeats = 75 if cfg.DATASET_NAME == "egobody" else (69 if cfg.DATASET_NAME == "gimo" else cfg.model.nfeats)
+    if datamodule is None and getattr(args, "data_root", None):
+        from .data import EgoDataModule
+        datamodule = EgoDataModule(args.data_root, cfg.DATASET_NAME, tuple(cfg.model.condition), motion_length=int(cfg.MOTION_LENGTH),
+                                   predict_transl=bool(cfg.TRAIN.ABLATION.PREDICT_TRANSL), device=dev, storage=args.storage,
+                                   scene_root=args.scene_root, pose_estimation_task=bool(cfg.TEST.get("POSE_ESTIMATION_TASK", False)))
     dm = datamodule or SyntheticEgoDataModule(nfeats=nfeats, T=args.frames, n_points=args.scene_points,
                                                seed=int(cfg.SEED_VALUE), device=dev)
     if smpl_model is None and not os.path.exists(str(cfg.model.smpl_path)):
@@ -231,7 +240,7 @@ def test_main(argv: Optional[List[str]] = None, datamodule=None, smpl_model=None
         t0 = time.perf_counter()
         with torch.no_grad():
             for it in range(args.test_batches):
-                batch = dm.batch(B, idx=10_000_000 + it * ws + rank, with_scene=_with_scene(cfg))
+                batch = dm.batch(B, idx=10_000_000 + it * ws + rank, with_scene=_with_scene(cfg), split="test")
                 model.test_step(batch, it)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0

@@ -209,7 +209,7 @@ class SyntheticEgoDataModule:
     def renorm(self, features):
         return G.renorm(features, self.mean, self.std)
 
-    def batch(self, B, idx=0, with_scene=False, lengths=None, pose_estimation=False):
+    def batch(self, B, idx=0, with_scene=False, lengths=None, pose_estimation=False, split="train"):
         g = torch.Generator().manual_seed(self.seed * 7919 + idx)
         T = self.T
         motion = 0.5 * torch.randn(B, T, 2, self.pose_dim, generator=g)

@@ -333,3 +333,41 @@ def test_capture_training_step_replay_equals_eager(dev):
             worst = max(worst, float((p.detach().double() - want).abs().max() / want.abs().max().clamp_min(1e-12)))
         assert worst < 1e-5, (it, worst)
         assert float(bucket.flat.abs().max()) > 0
+
+
+# ----------------------------------------------------------------------------- data module (f2) on the device
+def test_data_module_feeds_training_and_eval(dev, tmp_path):
+    """seeme_amd.data.EgoDataModule (the EgoBody on-disk layout, split resident in HBM) as the `datamodule` of MLD: renorm
+    against numpy, a stage-2 training step and a test step on its batches (scene + interactee conditions)."""
+    from test_data_module import write_dataset
+    from seeme_amd import data as D
+    from seeme_amd.config import parse_config
+    from seeme_amd.mld import MLD
+    from seeme_amd.smpl import SMPL
+    root = str(tmp_path / "egobody")
+    write_dataset(root, "egobody", n=9, T=12, P=64)
+    dm = D.EgoDataModule(root, "egobody", condition=("text", "scene", "interactee"), motion_length=12, device=dev, scene_root=root)
+    assert dm.splits["train"].motion.is_cuda and dm.splits["train"].scene_table.is_cuda
+    x = torch.randn(3, 12, 75, device=dev)
+    mean, std = np.load(os.path.join(root, "mean.npy")), np.load(os.path.join(root, "std.npy"))
+    assert rel_err(_np(dm.renorm(x)), _np(x) * std[0, :75] + mean[0, :75]) < 1e-6
+    cfg = parse_config(os.path.join(REPO, "configs", "config_mld_scene.yaml"))
+    cfg.model.scheduler.num_inference_timesteps = 5
+    model = MLD(cfg, dm, smpl_model=SMPL.synthetic(1234))
+    load_recipe_(model.vae), load_recipe_(model.denoiser), load_recipe_(model.proscene.scene_enc)
+    model = model.to(dev).train()
+    losses = []
+    for it in range(3):
+        batch = dm.batch(4, idx=it, split="train")
+        assert batch[0].shape == (4, 12, 2, 72) and batch[4].shape == (4, 64, 3) and batch[5].shape == (4, 1)
+        loss = model.training_step(batch)
+        model.optimizer_step(loss)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses))
+    model.eval()
+    model.EgoMetric.reset()
+    for b in dm.iterate("test", 4):
+        out = model.test_step(b)
+        assert out.shape[1:] == (12, 24, 3)
+    got = model.EgoMetric.compute()
+    assert np.isfinite(got["MPJPE"]) and got["count_seq"] > 0
