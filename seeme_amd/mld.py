@@ -487,7 +487,7 @@ class MLD(nn.Module):
             mu, std = vae_encode_torch(self.vae, f_ref, lengths)
             dist_m = torch.distributions.Normal(mu, std, validate_args=False)
             z = dist_m.rsample() if eps is None else mu + eps.to(mu) * std
-            m_rst = self.renorm(vae_decode_torch(self.vae, z, lengths))
+            m_rst = self.renorm(vae_decode_torch(self.vae, z, lengths))    # differentiable (geometry._Renorm)
             with torch.no_grad():
                 joints_ref = self._feats_to_joints(m_ref, beta[:, idx])[:, :, :nj]
             joints_rst = self._feats_to_joints_torch(m_rst, beta[:, idx], orient=ref_orient)[:, :, :nj]

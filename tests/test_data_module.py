@@ -12,8 +12,9 @@ import torch
 from seeme_amd import data as D
 
 
-def write_dataset(root, dataset="egobody", n=7, T=12, P=50, seed=0, with_scene=True):
-    """A tiny dataset in the reference's layout.  Sequences have ragged lengths <= T."""
+def write_dataset(root, dataset="egobody", n=7, T=12, P=50, seed=0, with_scene=True, full_every=None):
+    """A tiny dataset in the reference's layout.  Sequences have ragged lengths <= T (every `full_every`-th one is T long:
+    the VAE mask is built from max(lengths), so -- as in the reference -- a batch needs one full-length member)."""
     rng = np.random.default_rng(seed)
     pose = 69 if dataset == "egobody" else 63
     nd = 72 if dataset == "egobody" else 66
@@ -26,6 +27,8 @@ def write_dataset(root, dataset="egobody", n=7, T=12, P=50, seed=0, with_scene=T
         os.makedirs(os.path.join(root, split), exist_ok=True)
         for i in range(n):
             L = int(rng.integers(T // 2, T + 1))
+            if full_every and i % full_every == 0:
+                L = T
             seq = f"recording_{split}_{i // 2}"
             ts = [1000 + 7 * i + k for k in range(L)]
             if dataset == "egobody":

@@ -129,7 +129,11 @@ def test_train_vae_forward_and_losses_vs_oracle(dev, cfg_name):
             assert rel_err(_np(rs["joints_rst"]), want["joints_rst"]) < 5 * TOL_F32
             L = model.losses["train"]
             L.reset()
-            total = float(L.update(rs))
+            tot = L.update(rs)
+            total = float(tot.detach())
+        if grad:       # the feature term must reach the DECODER through the renorm (a HIP op with its own backward)
+            gd = torch.autograd.grad(tot, [model.vae.final_layer.weight, model.vae.skel_embedding.weight])
+            assert all(torch.isfinite(t).all() and float(t.abs().sum()) > 0 for t in gd)
         got = L.compute()
         for k in ("recons_feature", "recons_joints", "recons_transl", "kl_motion"):
             assert abs(got[k] - wl[k]) < 5e-4 * max(1e-3, abs(wl[k])), (grad, k, got[k], wl[k])
@@ -345,7 +349,7 @@ def test_data_module_feeds_training_and_eval(dev, tmp_path):
     from seeme_amd.mld import MLD
     from seeme_amd.smpl import SMPL
     root = str(tmp_path / "egobody")
-    write_dataset(root, "egobody", n=9, T=12, P=64)
+    write_dataset(root, "egobody", n=9, T=12, P=64, full_every=4)
     dm = D.EgoDataModule(root, "egobody", condition=("text", "scene", "interactee"), motion_length=12, device=dev, scene_root=root)
     assert dm.splits["train"].motion.is_cuda and dm.splits["train"].scene_table.is_cuda
     x = torch.randn(3, 12, 75, device=dev)
@@ -369,5 +373,9 @@ def test_data_module_feeds_training_and_eval(dev, tmp_path):
     for b in dm.iterate("test", 4):
         out = model.test_step(b)
         assert out.shape[1:] == (12, 24, 3)
+    assert np.isfinite(model.EgoMetric.compute()["MPJPE"])     # 'test' keeps only plausible sequences (compute.py:488-517):
+    model.EgoMetric.reset()                                    # random weights leave none, so count on the 'val' rule
+    for b in dm.iterate("test", 4):
+        model.validation_step(b)
     got = model.EgoMetric.compute()
     assert np.isfinite(got["MPJPE"]) and got["count_seq"] > 0
