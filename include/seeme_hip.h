@@ -328,6 +328,86 @@ int seeme_adamw_step_dev(const void* chunks, int n_chunks, void* const* params, 
                          void* const* exp_avg_sq, const float* step_lr, double beta1, double beta2, double eps,
                          double weight_decay, void* stream);
 
+/* ------------------------------------------------------------------ stage-2 training step: the work around the chain
+ * Replaces, for MLD.train_diffusion_forward / _diffusion_process (mld/models/modeltype/mld.py:582-631,887-1017), the
+ * PyTorch ops (and their autograd backward) that build the chain's inputs: posterior rsample (mld_vae.py:186-193),
+ * scheduler.add_noise (:604-606), the sinusoidal timestep features + TimestepEmbedding MLP (tools/embeddings.py:207-285),
+ * output_scene (mld.py:257-261) and MldDenoiser.forward's per-layer condition / time tables (mld_denoiser.py:150-256:
+ * self-attention K|V of the condition and time tokens, text_norm + linear-attention key|value, AdaLN scale|shift rows). */
+typedef struct {
+    int B, N;                 /* samples, condition tokens per sample */
+    const float* dist;        /* [2, dist_rows, 256]: row 0 mu, row 1 logvar (seeme_vae_encode_dist); rows [0,B) = target,
+                                 rows [B,2B) = condition motion when eps_c is set */
+    int dist_rows;
+    const float* eps_z;       /* [B,256] rsample noise of the target */
+    const float* eps_c;       /* [B,256] rsample noise of the condition latent, or NULL (no 'interactee' condition) */
+    int slot_c;               /* token slot of the condition latent in cond */
+    float* cond;              /* [B,N,256] condition tokens (slot_c written here) */
+    const float* noise;       /* [B,256] */
+    const int64_t* timesteps; /* [B] */
+    const float* acp;         /* alphas_cumprod [num_train_timesteps] */
+    const float* freq;        /* [128] exp(-ln(max_period) * j / (128 - freq_shift)) */
+    int flip_sin_to_cos;
+    float* latents;           /* [B,256] z */
+    float* noisy;             /* [B,256] x_t */
+    float* tfeat;             /* [B,256] */
+} SeemeGlueRows;
+int seeme_glue_rows(const SeemeGlueRows* a, void* stream);
+/* F.layer_norm(x, (256,)) without affine: xhat [M,256], rstd [M]. */
+int seeme_glue_ln(const float* x, float* xhat, float* rstd, int M, void* stream);
+
+/* One problem of seeme_grouped_gemm:  C[i,j] (+)= sum_s sum_{k < seg_len[s]} A_s[i,k] * B_s[k,j]  (+ bias[j]) (* epilogue)
+ * with A_s[i,k] = pro_a(a[s][i*a_rs + k*a_ks[s]]) and B_s[k,j] = pro_b(b[s][k*b_ks[s] + j*b_cs]); prologue modes: 0 none, 1 SiLU,
+ * 2 ReLU, 3 affine v*p0[idx] + p1[idx] (idx = k for A, j for B).  epi 1: multiply by SiLU'(e0[i*e_ld + j]).  colsum (needs
+ * a_rs == 1): colsum[i] (+)= sum_s sum_k a[s][i,k] -- the bias gradient that comes free with a weight gradient.  tile0 /
+ * tiles_n: position of the problem's 64x64 tiles in the launch. */
+typedef struct {
+    const float* a[10];
+    const float* b[10];
+    int seg_len[10];
+    long a_ks[10];
+    long b_ks[10];
+    int nseg;
+    long a_rs, b_cs;
+    float* c;
+    long ldc;
+    int M, N;
+    int a_pro;
+    const float* a_p0;
+    const float* a_p1;
+    int b_pro;
+    const float* b_p0;
+    const float* b_p1;
+    const float* bias;
+    int epi;
+    const float* e0;
+    long e_ld;
+    int accumulate;
+    float* colsum;
+    int tile0, tiles_n;
+} SeemeGemmProblem;
+int seeme_grouped_gemm(const SeemeGemmProblem* probs_dev, int n_probs, int n_tiles, void* stream);
+int seeme_gemm_problem_bytes(void);
+
+/* Element-wise middle of the backward: d cond = sum_l dcs[l] + LayerNorm-backward(sum_l dxl[l] * tn_w[l]); text_norm
+ * affine gradients g_tn_w[l] += sum_m dxl[l]*xhat, g_tn_b[l] += sum_m dxl[l]; d emb = sum_5 dea + SiLU'(emb) * sum_10 deb. */
+typedef struct {
+    int M, B;
+    const float* dxl;         /* [5,M,256] */
+    const float* dcs;         /* [5,M,256] */
+    const float* xhat;        /* [M,256] */
+    const float* rstd;        /* [M] */
+    const float* tn_w[5];
+    float* g_tn_w[5];
+    float* g_tn_b[5];
+    float* dcond;             /* [M,256] */
+    const float* dea;         /* [5,B,256] */
+    const float* deb;         /* [10,B,256] */
+    const float* emb;         /* [B,256] */
+    float* demb;              /* [B,256] */
+} SeemeGlueMid;
+int seeme_glue_mid(const SeemeGlueMid* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

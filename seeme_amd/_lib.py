@@ -102,10 +102,34 @@ class PointnetBf16(C.Structure):
     _fields_ = [("fc0", fp * 4), ("fc1", fp * 4), ("sc", fp * 4), ("posf", fp), ("sc3", fp), ("stream", fp * 4), ("sc3f", fp)]
 
 
+class GlueRows(C.Structure):
+    _fields_ = [("B", C.c_int), ("N", C.c_int), ("dist", fp), ("dist_rows", C.c_int), ("eps_z", fp), ("eps_c", fp),
+                ("slot_c", C.c_int), ("cond", fp), ("noise", fp), ("timesteps", fp), ("acp", fp), ("freq", fp),
+                ("flip_sin_to_cos", C.c_int), ("latents", fp), ("noisy", fp), ("tfeat", fp)]
+
+
+class GemmProblem(C.Structure):
+    _fields_ = [("a", fp * 10), ("b", fp * 10), ("seg_len", C.c_int * 10), ("a_ks", C.c_long * 10),
+                ("b_ks", C.c_long * 10), ("nseg", C.c_int), ("a_rs", C.c_long), ("b_cs", C.c_long), ("c", fp), ("ldc", C.c_long),
+                ("M", C.c_int), ("N", C.c_int), ("a_pro", C.c_int), ("a_p0", fp), ("a_p1", fp), ("b_pro", C.c_int),
+                ("b_p0", fp), ("b_p1", fp), ("bias", fp), ("epi", C.c_int), ("e0", fp), ("e_ld", C.c_long),
+                ("accumulate", C.c_int), ("colsum", fp), ("tile0", C.c_int), ("tiles_n", C.c_int)]
+
+
+class GlueMid(C.Structure):
+    _fields_ = [("M", C.c_int), ("B", C.c_int), ("dxl", fp), ("dcs", fp), ("xhat", fp), ("rstd", fp), ("tn_w", fp * 5),
+                ("g_tn_w", fp * 5), ("g_tn_b", fp * 5), ("dcond", fp), ("dea", fp), ("deb", fp), ("emb", fp), ("demb", fp)]
+
+
 GEO_AA_TO_QUAT, GEO_AA_TO_ROTMAT, GEO_QUAT_TO_ROTMAT, GEO_ROT6D_PROHMR, GEO_ROT6D_DIFFUSION = range(5)
 
 # name -> (restype, argtypes); every symbol of include/seeme_hip.h
 _SIGNATURES = {
+    "seeme_glue_rows": (C.c_int, [C.POINTER(GlueRows), fp]),
+    "seeme_glue_ln": (C.c_int, [fp, fp, fp, C.c_int, fp]),
+    "seeme_glue_mid": (C.c_int, [C.POINTER(GlueMid), fp]),
+    "seeme_grouped_gemm": (C.c_int, [fp, C.c_int, C.c_int, fp]),
+    "seeme_gemm_problem_bytes": (C.c_int, []),
     "seeme_version": (C.c_int, []),
     "seeme_last_error": (C.c_char_p, []),
     "seeme_linear": (C.c_int, [C.POINTER(LinearArgs), fp]),

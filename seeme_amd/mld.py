@@ -268,6 +268,7 @@ class MLD(nn.Module):
         if self.cfg_scene_order not in ("reference", "fixed"):
             raise ValueError("TEST.CFG_SCENE_ORDER must be 'reference' or 'fixed'")
         self.hip_backward = cfg.TRAIN.get("HIP_BACKWARD", True)   # hand-written backward of the denoiser chain (one head)
+        self.hip_glue = cfg.TRAIN.get("HIP_GLUE", True)           # ... and of everything around it (stage2_glue.py); needs HIP_BACKWARD
         self.pose_estimation_task = cfg.TEST.get("POSE_ESTIMATION_TASK", False)      # mld.py:116
         if self.name_dataset == "egobody":                               # mld.py:122-125
             self.nfeats = 75 if self.predict_transl else 72
@@ -345,13 +346,15 @@ class MLD(nn.Module):
         return [p for p in self.parameters() if p.requires_grad]
 
     # ------------------------------------------------------------------ condition assembly
-    def _scene_token(self, scene, cfg_mask_train=False, mask=None):
+    def _scene_token(self, scene, cfg_mask_train=False, mask=None, code_only=False):
         scene = scene.float()
         if cfg_mask_train and self.do_classifier_free_guidance:           # mld.py:917-919
             if mask is None:
                 mask = torch.rand_like(scene) < self.guidance_uncodp
             scene = torch.where(mask, torch.zeros_like(scene), scene)
         s512 = self.proscene.encode_scene(scene)                          # HIP PointNet
+        if code_only:
+            return s512
         # output_scene = ReLU + Linear(512,256) (trainable, mld.py:257-261): torch op so that autograd sees it
         return self.output_scene(s512).unsqueeze(0)                       # [1,B,256]
 
@@ -429,12 +432,17 @@ class MLD(nn.Module):
         e_z, e_c = eps if eps is not None else (None, None)
         if "scene" in self.condition:
             feats_ref, transl, beta, utils_, scene, length = batch[:6]
-            scene = self._scene_token(scene, cfg_mask_train=True, mask=m_scene)
+            scene = self._scene_token(scene, cfg_mask_train=True, mask=m_scene, code_only=True)      # [B,512] PointNet code
         else:
             feats_ref, transl, beta, utils_, length = batch[:5]
             scene = None
         feats_ref, transl = feats_ref.float(), transl.float()
         lengths = [feats_ref.shape[1]] * feats_ref.shape[0]
+        glue = self._stage2_glue(int(scene is not None) + int("interactee" in self.condition)) if feats_ref.is_cuda else None
+        if glue is not None:
+            return self._train_diffusion_forward_glue(glue, feats_ref, transl, scene, lengths, noise, timesteps, e_z, e_c, m_int)
+        if scene is not None:
+            scene = self.output_scene(scene).unsqueeze(0)                     # [1,B,256]
         with torch.no_grad():
             idx = 0 if self.estimate == "wearer" else 1
             f_tgt = self._wearer_features(feats_ref, transl, idx)
@@ -467,6 +475,48 @@ class MLD(nn.Module):
         else:
             raise ValueError("no condition: MldDenoiser needs at least one condition token")
         return {**self._diffusion_process(z, cond_emb, lengths, noise=noise, timesteps=timesteps)}
+
+    def _stage2_glue(self, n_tokens: int):
+        """The hand-written forward/backward around the chain (stage2_glue.Stage2Glue) when this step can take it."""
+        if not (self.hip_glue and self.hip_backward and torch.is_grad_enabled() and n_tokens >= 1):
+            return None
+        from .stage2_glue import Stage2Glue
+        if not any(p.requires_grad for p in self.denoiser.parameters()) or not Stage2Glue.supported(self, n_tokens):
+            return None
+        g = getattr(self, "_glue", None)
+        if g is None or g.stale():
+            g = Stage2Glue(self)
+            object.__setattr__(self, "_glue", g)
+        return g
+
+    def _train_diffusion_forward_glue(self, glue, feats_ref, transl, s512, lengths, noise, timesteps, e_z, e_c, m_int):
+        """train_diffusion_forward + _diffusion_process with everything between the frozen encoders and the loss in
+        stage2_glue's kernels; the random draws keep the reference's order (mld.py:917-919,944-984,591-601)."""
+        with torch.no_grad():
+            idx = 0 if self.estimate == "wearer" else 1
+            f_tgt = self._wearer_features(feats_ref, transl, idx)
+            B, dev = f_tgt.shape[0], f_tgt.device
+            draw = lambda e: torch.empty(B, 256, device=dev, dtype=torch.float32).normal_() if e is None else e.to(f_tgt).reshape(B, 256)
+            eps_z = draw(e_z)
+            eps_c = None
+            if "interactee" in self.condition:
+                f_int = self._wearer_features(feats_ref, transl, 1)
+                if self.do_classifier_free_guidance:                       # mld.py:966-981
+                    mask = (torch.rand_like(f_int) < self.guidance_uncodp) if m_int is None else m_int
+                    f_int = torch.where(mask, torch.zeros_like(f_int), f_int)
+                eps_c = draw(e_c)
+                dist = self.vae.encode_dist(torch.cat([f_tgt, f_int], dim=0), lengths + lengths)      # [2, 2B, 256]
+            else:
+                dist = self.vae.encode_dist(f_tgt, lengths)
+            noise = torch.randn(B, 1, 256, device=dev) if noise is None else noise.to(f_tgt)
+            if timesteps is None:
+                timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (B,), device=dev)
+        noise_pred, latents = glue(dist, eps_z, eps_c, noise, timesteps.long(), s512)
+        n_set = {"noise": noise.reshape(B, 1, 256), "noise_prior": 0, "noise_pred": noise_pred, "noise_pred_prior": 0}
+        if not self.predict_epsilon:
+            n_set["pred"] = noise_pred
+            n_set["latent"] = latents
+        return n_set
 
     # ------------------------------------------------------------------ stage-1 forward (mld.py:633-885)
     def train_vae_forward(self, batch, eps=None):

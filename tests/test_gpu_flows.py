@@ -379,3 +379,48 @@ def test_data_module_feeds_training_and_eval(dev, tmp_path):
         model.validation_step(b)
     got = model.EgoMetric.compute()
     assert np.isfinite(got["MPJPE"]) and got["count_seq"] > 0
+
+
+@pytest.mark.parametrize("cfg_name,B", [("config_mld_scene.yaml", 5), ("config_mld_gimo.yaml", 3), ("config_mld_egobody.yaml", 70)])
+def test_stage2_glue_matches_autograd_path(dev, cfg_name, B):
+    """stage2_glue (hand-written HIP forward + backward of rsample / add_noise / time MLP / output_scene / condition and
+    time tables, gradients accumulated straight into .grad) against the same step with those parts as torch ops under
+    autograd (TRAIN.HIP_GLUE false; itself pinned to the CPU oracle above): loss, noise prediction and EVERY parameter
+    gradient, for two tokens (interactee + scene), scene only and interactee only; B = 70 crosses a 64-row tile edge."""
+    with_scene = "scene" in cfg_name or "gimo" in cfg_name
+    got = []
+    for glue in (True, False):
+        def mut(cfg):
+            cfg.TRAIN.HIP_GLUE = glue
+        model, dm, cfg = _mld(dev, cfg_name, mutate=mut)
+        model.train()
+        tb = dm.batch(B, idx=3, with_scene=with_scene)
+        g = torch.Generator().manual_seed(5)
+        noise, ts = torch.randn(B, 1, 256, generator=g).to(dev), torch.randint(0, 1000, (B,), generator=g).to(dev)
+        eps = (torch.randn(1, B, 256, generator=g).to(dev), torch.randn(1, B, 256, generator=g).to(dev))
+        masks = None
+        if model.do_classifier_free_guidance:
+            ms = (torch.rand(B, dm.n_points, 3, generator=g) < 0.1).to(dev) if with_scene else None
+            mi = (torch.rand(B, 16, cfg.model.nfeats, generator=g) < 0.1).to(dev) if "interactee" in model.condition else None
+            masks = (ms, mi)
+        out = []
+        for it in range(2):                                  # twice: the second step runs on cached plans / descriptor tables
+            for p in model.parameters():
+                p.grad = None
+            rs = model.train_diffusion_forward(tb, noise=noise, timesteps=ts, eps=eps, masks=masks)
+            loss = model.losses["train"].update(rs)
+            loss.backward()
+            out.append((float(loss), rs["noise_pred"].detach().clone(),
+                        {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}))
+        assert (getattr(model, "_glue", None) is not None) == glue
+        got.append(out)
+    for it in range(2):
+        (l1, n1, g1), (l0, n0, g0) = got[0][it], got[1][it]
+        assert abs(l1 - l0) < 1e-5 * abs(l0), (it, l1, l0)
+        assert rel_err(_np(n1), _np(n0)) < 1e-5
+        assert set(g1) == set(g0), set(g1) ^ set(g0)
+        # (a key bias of the linear attention has a mathematically zero gradient -- softmax over the tokens is shift
+        # invariant -- so errors are measured against the largest gradient entry of the whole model, not per tensor)
+        scale = max(float(v.abs().max()) for v in g0.values())
+        errs = sorted(((float((g1[k] - g0[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-4 * scale), k) for k in g0), reverse=True)
+        assert errs[0][0] < 5e-5, (it, errs[:6])
