@@ -310,6 +310,10 @@ int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const SeemePointne
  * gout is the per-sample buffer of seeme_denoiser_backward (x and dy of every linear, csrc/den_train.h).  Replaces the
  * autograd weight-gradient accumulation of loss.backward() through MldDenoiser.forward (mld.py:582-631). */
 int seeme_den_wgrad(const float* gout, int ldg, int B, const void* tiles, int n_tiles, float* out, void* stream);
+/* The chain's vector gradients (biases, LayerNorm weights / biases) in one launch: out[q] = sum_b gout[b*ldg + idx[q]], q < n,
+ * and dpe_row0[c] = sum_b gout[b*ldg + dx0_col + c], c < 256 (query_pos.pe row 0; NULL to skip).  Same reference as above. */
+int seeme_den_vecgrad(const float* gout, int ldg, int B, const int64_t* idx, int n, float* out, int dx0_col, float* dpe_row0,
+                      void* stream);
 
 /* AdamW step of a list of fp32 tensors in one launch, torch.optim.AdamW arithmetic (amsgrad off): replaces the
  * optimiser step Lightning runs after training_step (reference: mld/models/modeltype/base.py configure_optimizers,

@@ -6,5 +6,5 @@ timeout -k 10 300 python bench.py --mode train --steps 20 > $O/bench_train_scene
 timeout -k 10 300 python bench.py --mode train --train-config gimo --steps 20 > $O/bench_train_gimo.json 2>/dev/null
 rm -rf gpurun_out/kt_t
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt_t -- python bench.py --mode train --steps 10 --warmup 3 > $O/kt_train.log 2>&1
-python scripts/steady_stats.py kt_t k_adamw 3 10 $O/kernel_stats_train_steady.csv
+python scripts/steady_stats.py kt_t k_adamw 3 10 $O/kernel_stats_train_steady.csv k_gg
 rm -rf gpurun_out/kt_t

@@ -23,6 +23,12 @@ for r in rows[lo:hi + 1]:
     k = r["Kernel_Name"].split("(")[0][:80]
     agg[k][0] += 1
     agg[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+detail = sys.argv[6] if len(sys.argv) > 6 else None       # kernel launched several times per step: average by position in the step
+if detail:
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows[lo:hi + 1] if r["Kernel_Name"].split("(")[0] == detail]
+    n = len(d) // steps
+    if n:
+        print(detail, "by position in the step (us):", [round(sum(d[i::n]) / len(d[i::n]), 1) for i in range(n)])
 tot = sum(v[1] for v in agg.values())
 mine = sum(v[1] for k, v in agg.items() if own(k))
 with open(out, "w") as f:

@@ -125,6 +125,7 @@ GEO_AA_TO_QUAT, GEO_AA_TO_ROTMAT, GEO_QUAT_TO_ROTMAT, GEO_ROT6D_PROHMR, GEO_ROT6
 
 # name -> (restype, argtypes); every symbol of include/seeme_hip.h
 _SIGNATURES = {
+    "seeme_den_vecgrad": (C.c_int, [fp, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, fp, fp]),
     "seeme_glue_rows": (C.c_int, [C.POINTER(GlueRows), fp]),
     "seeme_glue_ln": (C.c_int, [fp, fp, fp, C.c_int, fp]),
     "seeme_glue_mid": (C.c_int, [C.POINTER(GlueMid), fp]),

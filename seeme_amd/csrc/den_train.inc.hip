@@ -463,3 +463,24 @@ extern "C" int seeme_den_wgrad(const float* gout, int ldg, int B, const void* ti
     return seeme_check_launch("k_den_wgrad");
 }
 
+
+// Bias / LayerNorm gradients of the chain: out[q] = sum_b gout[b*ldg + idx[q]] (one gather-reduce instead of
+// column-sum + index_select + copies), and the one row of query_pos.pe that is on the path.
+__global__ __launch_bounds__(256) void k_den_vecgrad(const float* __restrict__ gout, int ldg, int B, const int64_t* __restrict__ idx,
+                                                     int n, float* __restrict__ out, int dx0_col, float* __restrict__ dpe_row0) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n + 256) return;
+    const long col = q < n ? idx[q] : dx0_col + (q - n);
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += gout[(long)b * ldg + col];
+    if (q < n) out[q] = s;
+    else if (dpe_row0) dpe_row0[q - n] = s;
+}
+
+extern "C" int seeme_den_vecgrad(const float* gout, int ldg, int B, const int64_t* idx, int n, float* out, int dx0_col,
+                                 float* dpe_row0, void* stream) {
+    if (B <= 0 || n <= 0 || !gout || !idx || !out) return seeme_fail("den_vecgrad: bad arguments");
+    hipLaunchKernelGGL(k_den_vecgrad, dim3((unsigned)((n + 256 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gout, ldg, B, idx, n,
+                       out, dx0_col, dpe_row0);
+    return seeme_check_launch("k_den_vecgrad");
+}

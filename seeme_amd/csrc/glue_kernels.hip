@@ -107,15 +107,13 @@ __global__ __launch_bounds__(256) void k_glue_mid(SeemeGlueMid a) {
 
 // ------------------------------------------------------------------ grouped GEMM
 #define GG_T 64
-#define GG_K 16
+#ifndef GG_K
+#define GG_K 64          // k-step: 16 loads of A and 16 of B in flight per thread -- the weights are cold in HBM every step
+#endif                   // (PointNet streams GBs in between), so the tile time is round trips, not FLOPs
+#define GG_E (GG_K / 4)  // elements of A (and of B) per thread per k-step
 #define GG_LD (GG_T + 4)
 
-__device__ __forceinline__ float gg_pro(int mode, float v, const float* p0, const float* p1, int idx) {
-    if (mode == 1) return silu_f(v);
-    if (mode == 2) return fmaxf(v, 0.f);
-    if (mode == 3) return v * p0[idx] + p1[idx];
-    return v;
-}
+typedef float __attribute__((address_space(1))) gfloat;
 
 __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__ probs, int n_probs) {
     __shared__ float As[GG_K][GG_LD];
@@ -132,72 +130,124 @@ __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__
     const SeemeGemmProblem& P = probs[s_prob];
     const int tile = blockIdx.x - P.tile0;
     const int i0 = (tile / P.tiles_n) * GG_T, j0 = (tile % P.tiles_n) * GG_T;
-    const bool a_icontig = (P.a_rs == 1), b_jcontig = (P.b_cs == 1);      // else k is taken as the contiguous one
-    // load coordinates of this thread (4 elements of A, 4 of B per k-step)
-    int ai[4], ak[4], bj[4], bk[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (a_icontig) { ai[r] = t & 63; ak[r] = (t >> 6) + 4 * r; } else { ak[r] = t & 15; ai[r] = (t >> 4) + 16 * r; }
-        if (b_jcontig) { bj[r] = t & 63; bk[r] = (t >> 6) + 4 * r; } else { bk[r] = t & 15; bj[r] = (t >> 4) + 16 * r; }
-    }
-    const bool want_cs = P.colsum != nullptr && j0 == 0;      // host guarantees a_rs == 1 there: ai is the same for the 4 elements
+    const int M = P.M, N = P.N, nseg = P.nseg, a_pro = P.a_pro, b_pro = P.b_pro;
+    const long a_rs = P.a_rs, b_cs = P.b_cs;
+    const bool a_icontig = (a_rs == 1), b_jcontig = (b_cs == 1);      // else k is taken as the contiguous one
+    // element e (0..GG_E-1) of this thread in a k-step: 16-wide k sub-block e/4, position e%4 inside the sub-block's 64 x 16
+    auto a_i = [&](int e) { return a_icontig ? (t & 63) : (t >> 4) + 16 * (e & 3); };
+    auto a_k = [&](int e) { return 16 * (e >> 2) + (a_icontig ? (t >> 6) + 4 * (e & 3) : (t & 15)); };
+    auto b_j = [&](int e) { return b_jcontig ? (t & 63) : (t >> 4) + 16 * (e & 3); };
+    auto b_k = [&](int e) { return 16 * (e >> 2) + (b_jcontig ? (t >> 6) + 4 * (e & 3) : (t & 15)); };
+    const bool want_cs = P.colsum != nullptr && j0 == 0;      // host guarantees a_rs == 1 there: one i per thread
     float csum = 0.f;
-    float ra[4], rb[4];
+    float ra[GG_E], rb[GG_E];
     int seg = 0, k0 = 0;
+    // loads are unconditional (offset clamped to element 0 when out of range, zeroed in stage()): a load under a divergent
+    // branch makes the compiler wait for it at the join, which serialises the 2 x GG_E round trips of a k-step
     auto fetch = [&]() {
-        const float* ap = P.a[seg];
-        const float* bp = P.b[seg];
+        // (pointers read from the descriptor are generic: cast to the global address space, or every access is a FLAT load
+        // that the compiler waits for one at a time)
+        const gfloat* ap = (const gfloat*)P.a[seg];
+        const gfloat* bp = (const gfloat*)P.b[seg];
         const int len = P.seg_len[seg];
         const long aks = P.a_ks[seg], bks = P.b_ks[seg];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = k0 + ak[r], i = i0 + ai[r];
-            float v = 0.f;
-            if (k < len && i < P.M) {
-                v = ap[(long)i * P.a_rs + (long)k * aks];
-                csum += v;
-                v = gg_pro(P.a_pro, v, P.a_p0, P.a_p1, k);
-            }
-            ra[r] = v;
-            const int kb = k0 + bk[r], j = j0 + bj[r];
-            float w = 0.f;
-            if (kb < len && j < P.N) w = gg_pro(P.b_pro, bp[(long)kb * bks + (long)j * P.b_cs], P.b_p0, P.b_p1, j);
-            rb[r] = w;
+        for (int e = 0; e < GG_E; ++e) {
+            const int k = k0 + a_k(e), i = i0 + a_i(e);
+            const long oa = (long)i * a_rs + (long)k * aks;
+            ra[e] = ap[(k < len && i < M) ? oa : 0];
+            const int kb = k0 + b_k(e), j = j0 + b_j(e);
+            const long ob = (long)kb * bks + (long)j * b_cs;
+            rb[e] = bp[(kb < len && j < N) ? ob : 0];
         }
     };
-    auto advance = [&]() {
-        k0 += GG_K;
-        if (k0 >= P.seg_len[seg]) { k0 = 0; ++seg; }
+    auto stage = [&](int kbase, int len) {       // prologues, zero padding, LDS (kbase / len of the FETCHED step)
+        // prologues as uniform branches around straight-line loops, so that the affine one batches its 2 x GG_E loads
+        if (a_pro == 3) {
+            const gfloat* p0 = (const gfloat*)P.a_p0;
+            const gfloat* p1 = (const gfloat*)P.a_p1;
+            float s0[GG_E], s1[GG_E];
+#pragma unroll
+            for (int e = 0; e < GG_E; ++e) { const int q = min(kbase + a_k(e), len - 1); s0[e] = p0[q]; s1[e] = p1[q]; }
+#pragma unroll
+            for (int e = 0; e < GG_E; ++e) ra[e] = ra[e] * s0[e] + s1[e];
+        } else if (a_pro == 1) {
+#pragma unroll
+            for (int e = 0; e < GG_E; ++e) ra[e] = silu_f(ra[e]);
+        } else if (a_pro == 2) {
+#pragma unroll
+            for (int e = 0; e < GG_E; ++e) ra[e] = fmaxf(ra[e], 0.f);
+        }
+        if (b_pro == 3) {
+            const gfloat* p0 = (const gfloat*)P.b_p0;
+            const gfloat* p1 = (const gfloat*)P.b_p1;
+            float s0[GG_E], s1[GG_E];
+#pragma unroll
+            for (int e = 0; e < GG_E; ++e) { const int q = min(j0 + b_j(e), N - 1); s0[e] = p0[q]; s1[e] = p1[q]; }
+#pragma unroll
+            for (int e = 0; e < GG_E; ++e) rb[e] = rb[e] * s0[e] + s1[e];
+        } else if (b_pro == 1) {
+#pragma unroll
+            for (int e = 0; e < GG_E; ++e) rb[e] = silu_f(rb[e]);
+        } else if (b_pro == 2) {
+#pragma unroll
+            for (int e = 0; e < GG_E; ++e) rb[e] = fmaxf(rb[e], 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < GG_E; ++e) {
+            const int k = a_k(e), kb = b_k(e);
+            const bool oka = kbase + k < len && i0 + a_i(e) < M, okb = kbase + kb < len && j0 + b_j(e) < N;
+            if (oka) csum += ra[e];              // colsum problems have no A prologue (checked on the host)
+            As[k][a_i(e)] = oka ? ra[e] : 0.f;
+            Bs[kb][b_j(e)] = okb ? rb[e] : 0.f;
+        }
     };
     float acc[4][4] = {};
     const int ty = t >> 4, tx = t & 15;
     fetch();
-    while (seg < P.nseg) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { As[ak[r]][ai[r]] = ra[r]; Bs[bk[r]][bj[r]] = rb[r]; }
+    while (seg < nseg) {
+        stage(k0, P.seg_len[seg]);
         __syncthreads();
-        advance();
-        if (seg < P.nseg) fetch();
+        k0 += GG_K;
+        if (k0 >= P.seg_len[seg]) { k0 = 0; ++seg; }
+        if (seg < nseg) fetch();
+        // fragments of 4 k at a time, the next 4 in flight while these are multiplied: with one wave per SIMD nothing else
+        // hides the LDS latency (a read-wait-multiply loop ran at ~230 cycles per k)
+        float4 fa[2][4], fb[2][4];
 #pragma unroll
-        for (int k = 0; k < GG_K; ++k) {
-            const float4 av = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
-            const float4 bv = *reinterpret_cast<const float4*>(&Bs[k][tx * 4]);
-            const float aa[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        for (int q = 0; q < 4; ++q) {
+            fa[0][q] = *reinterpret_cast<const float4*>(&As[q][ty * 4]);
+            fb[0][q] = *reinterpret_cast<const float4*>(&Bs[q][tx * 4]);
+        }
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
+        for (int c = 0; c < GG_K / 4; ++c) {
+            if (c + 1 < GG_K / 4) {
 #pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] = fmaf(aa[x], bb[y], acc[x][y]);
+                for (int q = 0; q < 4; ++q) {
+                    fa[(c + 1) & 1][q] = *reinterpret_cast<const float4*>(&As[4 * (c + 1) + q][ty * 4]);
+                    fb[(c + 1) & 1][q] = *reinterpret_cast<const float4*>(&Bs[4 * (c + 1) + q][tx * 4]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 av = fa[c & 1][q], bv = fb[c & 1][q];
+                const float aa[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) acc[x][y] = fmaf(aa[x], bb[y], acc[x][y]);
+            }
         }
         __syncthreads();
     }
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
         const int i = i0 + ty * 4 + x;
-        if (i >= P.M) continue;
+        if (i >= M) continue;
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
             const int j = j0 + tx * 4 + y;
-            if (j >= P.N) continue;
+            if (j >= N) continue;
             float v = acc[x][y];
             if (P.bias) v += P.bias[j];
             if (P.epi == 1) v *= dsilu_f(P.e0[(long)i * P.e_ld + j]);
@@ -208,7 +258,7 @@ __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__
     if (want_cs) {
         cs[t >> 6][t & 63] = csum;
         __syncthreads();
-        if (t < GG_T && i0 + t < P.M) {
+        if (t < GG_T && i0 + t < M) {
             const float v = cs[0][t] + cs[1][t] + cs[2][t] + cs[3][t];
             P.colsum[i0 + t] = P.accumulate ? P.colsum[i0 + t] + v : v;
         }

@@ -198,11 +198,11 @@ class TrainPack:
         B = gout.shape[0]
         DBL = self.lay["DB_LAYER"]
         if self.bound and gout.is_cuda:
-            colsum = gout.sum(0)
             L.check(L.lib().seeme_den_wgrad(gout.data_ptr(), gout.shape[1], B, self._wgrad_tiles.data_ptr(), self._n_wgrad_tiles,
                                             self.gflat.data_ptr(), L.current_stream()), "seeme_den_wgrad")
-            self.vec_region.copy_(colsum.index_select(0, self.gather_idx))
-            self.dpe[0, 0].copy_(colsum[self.dx0_span[0]:self.dx0_span[1]])
+            L.check(L.lib().seeme_den_vecgrad(gout.data_ptr(), gout.shape[1], B, self.gather_idx.data_ptr(), self.gather_idx.numel(),
+                                              self.vec_region.data_ptr(), self.dx0_span[0], self.dpe.data_ptr(), L.current_stream()),
+                    "seeme_den_vecgrad")
             if self._attached:                                 # GradBucket.prepare() made .grad these very views
                 self._attached = False
                 return

@@ -351,7 +351,7 @@ class MLD(nn.Module):
         if cfg_mask_train and self.do_classifier_free_guidance:           # mld.py:917-919
             if mask is None:
                 mask = torch.rand_like(scene) < self.guidance_uncodp
-            scene = torch.where(mask, torch.zeros_like(scene), scene)
+            scene = scene.masked_fill(mask, 0.0)
         s512 = self.proscene.encode_scene(scene)                          # HIP PointNet
         if code_only:
             return s512
@@ -458,7 +458,7 @@ class MLD(nn.Module):
                 f_int = self._wearer_features(feats_ref, transl, 1)
                 if self.do_classifier_free_guidance:                       # mld.py:966-981
                     mask = (torch.rand_like(f_int) < self.guidance_uncodp) if m_int is None else m_int
-                    f_int = torch.where(mask, torch.zeros_like(f_int), f_int)
+                    f_int = f_int.masked_fill(mask, 0.0)
                 eps_c = draw(e_c)
                 dist = self.vae.encode_dist(torch.cat([f_tgt, f_int], dim=0), lengths + lengths)      # [2, 2B, 256]
                 mu, std = dist[0:1], dist[1:2].exp().pow(0.5)              # mld_vae.py:186-190
@@ -503,7 +503,7 @@ class MLD(nn.Module):
                 f_int = self._wearer_features(feats_ref, transl, 1)
                 if self.do_classifier_free_guidance:                       # mld.py:966-981
                     mask = (torch.rand_like(f_int) < self.guidance_uncodp) if m_int is None else m_int
-                    f_int = torch.where(mask, torch.zeros_like(f_int), f_int)
+                    f_int = f_int.masked_fill(mask, 0.0)
                 eps_c = draw(e_c)
                 dist = self.vae.encode_dist(torch.cat([f_tgt, f_int], dim=0), lengths + lengths)      # [2, 2B, 256]
             else:

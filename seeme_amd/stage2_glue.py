@@ -38,8 +38,8 @@ class _Group:
         for p in probs:
             n, tn = _tiles(p.M, p.N)
             p.tile0, p.tiles_n = t0, tn
-            if p.colsum and p.a_rs != 1:
-                raise ValueError("colsum needs an i-contiguous A")
+            if p.colsum and (p.a_rs != 1 or p.a_pro):
+                raise ValueError("colsum needs an i-contiguous A without a prologue")
             t0 += n
         arr = (L.GemmProblem * len(probs))(*probs)
         assert C.sizeof(L.GemmProblem) == L.lib().seeme_gemm_problem_bytes(), "GemmProblem layout mismatch with the library"
