@@ -741,6 +741,347 @@ static int launch_ffn_h(const FfnHArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_layer_h: ONE kernel per transformer layer.  Everything after the QKV projection of a layer is local to a 32-row tile
+// (attention reads all keys / values of its sequence, but writes only its own rows), and so is the QKV projection of the
+// NEXT layer -- so a workgroup runs, for its 32 query rows:
+//   attention -> out_proj -> +residual -> LN1 [-> +cross-attention vector -> LN (decoder)] -> FFN -> +residual -> LN
+//   [-> stack LN] [-> skip linear W.cat(x, skip rows) + b] [-> q | k | V^T of the next layer] [-> final projection]
+// and the next launch finds q | k | V^T of all rows in the OTHER buffer set.  Against attn + ffn + qkv launches: a third of
+// the launches, the intermediate rows (mid, x) never leave the CU, and no V^T memset (the padding columns are written here).
+// LDS: R0 = [32][Sp+8] fp32 (scores -> out_proj tile -> hidden operand -> FFN output tile -> tail tiles), R1 = [32][272]
+// fp16 (Q -> O -> x operand -> hidden -> x operand): 51 KB at Sp = 256, three workgroups per CU.  LN1's output rows stay in
+// registers (8 float4 per lane) as the FFN residual.
+struct LayerHArgs {
+    const unsigned short* qk; const unsigned short* vt; const float* res;
+    const uint4* wo; const float* bo; const float* n1_w; const float* n1_b;
+    const int32_t* lengths;
+    int S, n_prefix, q_rows, Sp, spv; float scale, eps;
+    const float* cvec; int cvec_ld; const float* lnc_w; const float* lnc_b;
+    const uint4* w1; const float* b1; const uint4* w2; const float* b2; const float* n2_w; const float* n2_b;
+    const float* fin_w; const float* fin_b;
+    float* out; int out_mode, B;
+    const uint4* skip_w; const float* skip_b; const float* skip_src; float* xnext;
+    const uint4* qkv_w; const float* qkv_b; unsigned short* qk_out; unsigned short* vt_out;
+    const uint4* proj_w; const float* proj_b; float* feats; int F;
+};
+
+__device__ __forceinline__ void rows_to_h16(unsigned short* Xh, int ldh, int row, int lane, float4 v) {
+    const unsigned lo = (unsigned)f2h(v.x) | ((unsigned)f2h(v.y) << 16), hi = (unsigned)f2h(v.z) | ((unsigned)f2h(v.w) << 16);
+    *reinterpret_cast<uint2*>(Xh + row * ldh + lane * 4) = make_uint2(lo, hi);
+}
+
+// q | k | V^T of a 32-row tile (fp16 operand rows in Xh) for the layer that runs next: q | k as fp16 rows, V transposed; the
+// padding columns [S, spv) of V^T are written as zeros (the tiles of a sequence cover them), so no memset is needed.
+__device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned short* Oh, const uint4* __restrict__ qkv_w,
+                                              const float* __restrict__ qkv_b, unsigned short* __restrict__ qk_out,
+                                              unsigned short* __restrict__ vt_out, int b, int q0, int S, int spv, BRing<4, H16_PF>& ring_t) {
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int ldq = 256 + HPAD;
+    const size_t base = (size_t)b * S;
+    for (int y = 0; y < 3; ++y) {
+        f32x4 acc[2][4];
+        acc_zero(acc);
+        const BiasRegs<4> bias = bias_load<4>(qkv_b, y * 256 + wave * 64, 768);
+        gemm_packed<2, 4>(Xh, ldq, qkv_w, 8, y * 16 + wave * 4, 48, 8, acc, ring_t);
+        if (y < 2) prime_packed(ring_t, qkv_w, 8, (y + 1) * 16 + wave * 4, 48, 8);
+        __syncthreads();                    // the previous part's stores have read the output tile
+        acc_store_h16<2, 4>(acc, Oh, ldq, wave * 64, bias, SEEME_ACT_NONE);
+        __syncthreads();
+        if (y < 2) {
+            for (int idx = tid; idx < TILE_M * 32; idx += 256) {
+                const int row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
+                if (s < S) *reinterpret_cast<uint4*>(qk_out + (base + s) * 512 + y * 256 + c8) = *reinterpret_cast<const uint4*>(Oh + row * ldq + c8);
+            }
+        } else {                            // V^T [b][d][s]: lanes <-> rows
+            const int row = tid & 31, dg = tid >> 5, s = q0 + row;
+            if (s < spv) {
+                unsigned short* vb = vt_out + ((size_t)b * 256) * spv + s;
+#pragma unroll 8
+                for (int j = 0; j < 32; ++j) {
+                    const int d = dg * 32 + j;
+                    vb[(size_t)d * spv] = s < S ? Oh[row * ldq + d] : (unsigned short)0;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_layer_h(const LayerHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
+    const int ldp = a.Sp + LDS_PAD, ldq = 256 + HPAD, ldph = 2 * ldp, ldc = 256 + LDS_PAD;
+    float* R0 = smem;
+    unsigned short* R1 = reinterpret_cast<unsigned short*>(R0 + TILE_M * ldp);
+    float* Ps = R0;
+    unsigned short* Ph = reinterpret_cast<unsigned short*>(R0);
+    unsigned short* Qh = R1;
+    int b = blockIdx.y, qt = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {    // all query tiles of one sequence on one XCD (speed only)
+        const int L = blockIdx.x + gridDim.x * blockIdx.y, rr = L & 7, q = L >> 3;
+        b = rr + 8 * (q / (int)gridDim.x);
+        qt = q % (int)gridDim.x;
+    }
+    const int q0 = qt * TILE_M;
+    const size_t base = (size_t)b * a.S;
+    const int n_valid_keys = min(a.S, a.n_prefix + a.lengths[b]);
+    const BiasRegs<4> bias_o = bias_load<4>(a.bo, wave * 64, 256);
+    BRing<4, ATT_PF> ring_o;
+    prime_packed(ring_o, a.wo, 8, wave * 4, 16, 8);
+    {   // Q tile
+        uint4 qv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + it * 256, row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
+            qv[it] = *reinterpret_cast<const uint4*>(a.qk + (base + (s < a.q_rows ? s : 0)) * 512 + c8);
+            if (s >= a.q_rows) qv[it] = make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + it * 256, row = idx >> 5, c8 = (idx & 31) * 8;
+            *reinterpret_cast<uint4*>(Qh + row * ldq + c8) = qv[it];
+        }
+    }
+    __syncthreads();
+    const unsigned short* Kmat = a.qk + base * 512 + 256;
+    for (int c0 = 0; c0 < a.Sp; c0 += CH_N) {
+        const int n0 = c0 + wave * 64;
+        f32x4 acc[2][4];
+        acc_zero(acc);
+        if (n0 < a.S) gemm_rows<2, 4, ATT_PF>(Qh, ldq, Kmat, 512, n0, a.S, 8, acc);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int c = n0 + nt * 16 + r;
+            const bool ok = c < n_valid_keys;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Ps[(mt * 16 + 4 * kq + i) * ldp + c] = ok ? acc[mt][nt][i] * a.scale : -INFINITY;
+        }
+    }
+    __syncthreads();
+    if (a.Sp == 256) attn_softmax_rows<4>(Ps, ldp, Ph, ldph, wave, lane);
+    else attn_softmax_rows<8>(Ps, ldp, Ph, ldph, wave, lane);
+    __syncthreads();
+    {   // O = P V
+        f32x4 acc[2][4];
+        acc_zero(acc);
+        const int K32 = (n_valid_keys + 31) >> 5;
+        gemm_rows<2, 4, ATT_PF>(Ph, ldph, a.vt + (size_t)b * 256 * a.spv, a.spv, wave * 64, 256, K32, acc);
+        acc_store_h16<2, 4>(acc, Qh, ldq, wave * 64, nullptr, SEEME_ACT_NONE);
+    }
+    __syncthreads();
+    float* Cs = R0;
+    {
+        f32x4 acc[2][4];
+        acc_zero(acc);
+        gemm_packed<2, 4, ATT_PF>(Qh, ldq, a.wo, 8, wave * 4, 16, 8, acc, ring_o);
+        acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, bias_o, SEEME_ACT_NONE);
+    }
+    // FFN weights requested now: their cold miss overlaps LN1
+    const BiasRegs<2> bias1 = bias_load<2>(a.b1, wave * 32, 128);
+    const BiasRegs<4> bias2 = bias_load<4>(a.b2, wave * 64, 256);
+    BRing<2, FFN_PF> ring1;
+    BRing<4, H16_PF> ring2;
+    prime_packed(ring1, a.w1, 8, wave * 2, 8, 8);
+    prime_packed(ring2, a.w2, 4, wave * 4, 16, 4);
+    __syncthreads();
+    unsigned short* Xh = R1;
+    float4 x1[8];
+    {   // +residual, LN1 [, + cross-attention vector, LN]; rows stay in registers, fp16 copy is the FFN operand
+        const LnParams lp = ln_params256(a.n1_w, a.n1_b), lc = ln_params256(a.lnc_w, a.lnc_b);
+        float4 xr[8];
+        float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.cvec != nullptr) cv = *reinterpret_cast<const float4*>(a.cvec + (size_t)b * a.cvec_ld + lane * 4);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int s = q0 + wave * 8 + rr;
+            xr[rr] = *reinterpret_cast<const float4*>(a.res + (base + (s < a.q_rows ? s : 0)) * 256 + lane * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr, s = q0 + row;
+            float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + lane * 4);
+            v = make_float4(v.x + xr[rr].x, v.y + xr[rr].y, v.z + xr[rr].z, v.w + xr[rr].w);
+            v = wave_layernorm256(v, lp, a.eps);
+            if (a.cvec != nullptr) {
+                v = make_float4(v.x + cv.x, v.y + cv.y, v.z + cv.z, v.w + cv.w);
+                v = wave_layernorm256(v, lc, a.eps);
+            }
+            if (s >= a.q_rows) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            x1[rr] = v;
+            rows_to_h16(Xh, ldq, row, lane, v);
+        }
+    }
+    __syncthreads();
+    unsigned short* Hh = R1;                     // hidden [32][144] overwrites the operand once every wave has read it
+    const int ldhh = 128 + HPAD;
+    {
+        f32x4 acc1[2][2];
+        acc_zero(acc1);
+        gemm_packed<2, 2, FFN_PF>(Xh, ldq, a.w1, 8, wave * 2, 8, 8, acc1, ring1);
+        __syncthreads();
+        acc_store_h16<2, 2>(acc1, Hh, ldhh, wave * 32, bias1, SEEME_ACT_GELU);
+    }
+    __syncthreads();
+    {
+        f32x4 acc2[2][4];
+        acc_zero(acc2);
+        gemm_packed<2, 4>(Hh, ldhh, a.w2, 4, wave * 4, 16, 4, acc2, ring2);
+        acc_store_lds<2, 4>(acc2, Cs, ldc, wave * 64, bias2, SEEME_ACT_NONE);
+    }
+    // tail weights requested now
+    const bool has_tail = a.skip_w != nullptr || a.qkv_w != nullptr || a.proj_w != nullptr;
+    BRing<4, H16_PF> ring_t;
+    if (a.skip_w != nullptr) prime_packed(ring_t, a.skip_w, 16, wave * 4, 16, 8);
+    else if (a.qkv_w != nullptr) prime_packed(ring_t, a.qkv_w, 8, wave * 4, 48, 8);
+    else if (a.proj_w != nullptr) prime_packed(ring_t, a.proj_w, 8, wave * 4, (a.F + 15) >> 4, 8);
+    __syncthreads();
+    {   // +residual, LN [, stack LN]; layer output rows
+        const LnParams lp = ln_params256(a.n2_w, a.n2_b), lf = ln_params256(a.fin_w, a.fin_b);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr, s = q0 + row;
+            float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + lane * 4);
+            v = make_float4(v.x + x1[rr].x, v.y + x1[rr].y, v.z + x1[rr].z, v.w + x1[rr].w);
+            v = wave_layernorm256(v, lp, a.eps);
+            if (a.fin_w != nullptr) v = wave_layernorm256(v, lf, a.eps);
+            if (s >= a.q_rows) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.out != nullptr && s < a.q_rows) {
+                const size_t orow = a.out_mode == 1 ? (size_t)s * a.B + b : base + s;
+                *reinterpret_cast<float4*>(a.out + orow * 256 + lane * 4) = v;
+            }
+            if (has_tail) rows_to_h16(Xh, ldq, row, lane, v);
+        }
+    }
+    if (!has_tail) return;
+    __syncthreads();
+    if (a.skip_w != nullptr) {   // x = W_skip . cat(x, skip rows) + b : two K = 256 halves, the second operand tile in R0
+        unsigned short* Sh = reinterpret_cast<unsigned short*>(R0);
+        {
+            float4 sv[8];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int s = q0 + wave * 8 + rr;
+                sv[rr] = *reinterpret_cast<const float4*>(a.skip_src + (base + (s < a.S ? s : 0)) * 256 + lane * 4);
+                if (s >= a.S) sv[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) rows_to_h16(Sh, ldq, wave * 8 + rr, lane, sv[rr]);
+        }
+        const BiasRegs<4> bias_s = bias_load<4>(a.skip_b, wave * 64, 256);
+        __syncthreads();
+        f32x4 acc[2][4];
+        acc_zero(acc);
+        gemm_packed<2, 4>(Xh, ldq, a.skip_w, 16, wave * 4, 16, 8, acc, ring_t);
+        gemm_packed<2, 4>(Sh, ldq, a.skip_w + 8 * 64, 16, wave * 4, 16, 8, acc);
+        if (a.qkv_w != nullptr) prime_packed(ring_t, a.qkv_w, 8, wave * 4, 48, 8);
+        __syncthreads();
+        acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, bias_s, SEEME_ACT_NONE);
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr, s = q0 + row;
+            float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + lane * 4);
+            if (s >= a.S) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s < a.S) *reinterpret_cast<float4*>(a.xnext + (base + s) * 256 + lane * 4) = v;
+            rows_to_h16(Xh, ldq, row, lane, v);
+        }
+        __syncthreads();
+    }
+    if (a.qkv_w != nullptr) {    // q | k | V^T of the next layer for these rows, into the other buffer set
+        tail_qkv_rows(Xh, reinterpret_cast<unsigned short*>(R0), a.qkv_w, a.qkv_b, a.qk_out, a.vt_out, b, q0, a.S, a.spv, ring_t);
+        return;
+    }
+    if (a.proj_w != nullptr) {   // final projection to the feature width (decoder): the stack LN was applied above
+        const int ntiles = (a.F + 15) >> 4;
+        const BiasRegs<4> bias = bias_load<4>(a.proj_b, wave * 64, a.F);
+        f32x4 acc[2][4];
+        acc_zero(acc);
+        if (wave * 4 < ntiles) gemm_packed<2, 4>(Xh, ldq, a.proj_w, 8, wave * 4, ntiles, 8, acc, ring_t);
+        acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, bias, SEEME_ACT_NONE);
+        __syncthreads();
+        for (int idx = tid; idx < TILE_M * 256; idx += 256) {
+            const int row = idx >> 8, c = idx & 255, s = q0 + row;
+            if (s < a.S && c < a.F) a.feats[(base + s) * a.F + c] = Cs[row * ldc + c];
+        }
+    }
+}
+
+static int launch_layer_h(const LayerHArgs& a_in, hipStream_t st) {
+    LayerHArgs a = a_in;
+    if (a.S <= 0 || a.S > 512) return seeme_fail("layer_h: S must be in 1..512");
+    a.Sp = (a.S + CH_N - 1) / CH_N * CH_N;
+    const size_t lds = (size_t)TILE_M * (a.Sp + LDS_PAD) * 4 + (size_t)TILE_M * (256 + HPAD) * 2;
+    dim3 grid((a.q_rows + TILE_M - 1) / TILE_M, a.B);
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_layer_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_layer_h, grid, dim3(256), lds, st, a);
+    return seeme_check_launch("k_layer_h");
+}
+
+
+// k_vae_pro_h: the input rows of the first layer and its q | k | V^T in one launch.  mode 1 (encoder): rows 0,1 = distribution
+// tokens + PE, rows 2.. = skel_embedding(features) + PE (mld_vae.py:143-160); mode 2 (decoder): the learned query PE rows
+// (:213-222, the queries are zeros + PE).
+struct ProHArgs {
+    int mode, B, S, T, F, spv;
+    const float* features; const uint4* emb_w; const float* emb_b; const float* token; const float* pe;
+    float* x;
+    const uint4* qkv_w; const float* qkv_b; unsigned short* qk_out; unsigned short* vt_out;
+};
+__global__ __launch_bounds__(256) void k_vae_pro_h(const ProHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ldq = 256 + HPAD, ldc = 256 + LDS_PAD;
+    float* Cs = smem;
+    unsigned short* R1 = reinterpret_cast<unsigned short*>(Cs + TILE_M * ldc);
+    const int b = blockIdx.y, q0 = blockIdx.x * TILE_M;
+    const size_t base = (size_t)b * a.S;
+    BRing<4, H16_PF> ring_t;
+    if (a.mode == 1) {
+        const int Kp = (a.F + 31) & ~31, lda_h = Kp + HPAD;
+        const BiasRegs<4> bias = bias_load<4>(a.emb_b, wave * 64, 256);
+        for (int idx = tid; idx < TILE_M * Kp; idx += 256) {       // features of frame s - 2 (guard: select on address and value)
+            const int row = idx / Kp, c = idx - row * Kp, s = q0 + row;
+            const bool ok = s >= 2 && s < a.S && c < a.F;
+            float v = a.features[ok ? ((size_t)b * a.T + (s - 2)) * a.F + c : 0];
+            R1[row * lda_h + c] = f2h(ok ? v : 0.f);
+        }
+        __syncthreads();
+        f32x4 acc[2][4];
+        acc_zero(acc);
+        gemm_packed<2, 4>(R1, lda_h, a.emb_w, Kp >> 5, wave * 4, 16, Kp >> 5, acc);
+        acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, bias, SEEME_ACT_NONE);
+    }
+    prime_packed(ring_t, a.qkv_w, 8, wave * 4, 48, 8);
+    __syncthreads();
+    unsigned short* Xh = R1;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr, s = q0 + row, sc = s < a.S ? s : 0;
+        float4 v = *reinterpret_cast<const float4*>(a.pe + (size_t)sc * 256 + lane * 4);
+        if (a.mode == 1) {
+            const float4 e = s < 2 ? *reinterpret_cast<const float4*>(a.token + (size_t)sc * 256 + lane * 4)
+                                   : *reinterpret_cast<const float4*>(Cs + row * ldc + lane * 4);
+            v = make_float4(v.x + e.x, v.y + e.y, v.z + e.z, v.w + e.w);
+        }
+        if (s >= a.S) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        else *reinterpret_cast<float4*>(a.x + (base + s) * 256 + lane * 4) = v;
+        rows_to_h16(Xh, ldq, row, lane, v);
+    }
+    __syncthreads();
+    tail_qkv_rows(Xh, reinterpret_cast<unsigned short*>(Cs), a.qkv_w, a.qkv_b, a.qk_out, a.vt_out, b, q0, a.S, a.spv, ring_t);
+}
+static int launch_pro_h(const ProHArgs& a, hipStream_t st) {
+    if (a.mode == 1 && a.F > 256) return seeme_fail("vae_pro_h: nfeats > 256");
+    const size_t lds = (size_t)TILE_M * (256 + LDS_PAD) * 4 + (size_t)TILE_M * (256 + HPAD) * 2;
+    dim3 grid((a.S + TILE_M - 1) / TILE_M, a.B);
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_vae_pro_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_vae_pro_h, grid, dim3(256), lds, st, a);
+    return seeme_check_launch("k_vae_pro_h");
+}
+
+// ---------------------------------------------------------------------------------------------
 // host sequencing (mirrors vae_kernels.hip)
 __global__ void k_enc_tokens_h(const float* __restrict__ token, const float* __restrict__ pe, float* __restrict__ x, int B, int S) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -809,7 +1150,7 @@ static int skip_lin_h(hipStream_t st, const float* a1, const float* a2, const ui
     return launch_linear_h(ha, st);
 }
 
-int seeme_vae_encode_h16(const SeemeVaeWeights* w, const float* features, const int32_t* lengths, int B, int T, float* mu,
+static int vae_encode_h16_unfused(const SeemeVaeWeights* w, const float* features, const int32_t* lengths, int B, int T, float* mu,
                          void* workspace, hipStream_t st) {
     const SeemeVaeWeightsH* H = w->h16;
     const int S = T + 2, F = w->nfeats;
@@ -836,7 +1177,7 @@ int seeme_vae_encode_h16(const SeemeVaeWeights* w, const float* features, const 
     return run_layer_h(st, E.layer[4], H->enc[4], ws.x, ws.y, mu, ws, lengths, B, S, 2, 2, nullptr, 0, E.norm_w, E.norm_b, 1);
 }
 
-int seeme_vae_decode_h16(const SeemeVaeWeights* w, const float* z, const int32_t* lengths, int B, int T, float* feats,
+static int vae_decode_h16_unfused(const SeemeVaeWeights* w, const float* z, const int32_t* lengths, int B, int T, float* feats,
                          void* workspace, hipStream_t st) {
     const SeemeVaeWeightsH* H = w->h16;
     const int S = T, F = w->nfeats;
@@ -860,4 +1201,140 @@ int seeme_vae_decode_h16(const SeemeVaeWeights* w, const float* z, const int32_t
     if ((rc = skip_lin_h(st, ws.x, ws.sk0, H->dec_skip[1], Dk.skip_b[1], ws.x, B * S))) return rc;
     if ((rc = run_layer_h(st, Dk.layer[4], H->dec[4], ws.x, ws.y, ws.x, ws, lengths, B, S, 0, S, ws.cvec + 4 * 256, CL, nullptr, nullptr, 0))) return rc;
     return lin_h(st, ws.x, 256, H->fin_w, 256, F, w->fin_b, feats, F, B * S, Dk.norm_w, Dk.norm_b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One kernel per layer (k_layer_h); SEEME_VAE_FUSED=0 selects the three-kernels-per-layer sequence above.
+static int vae_fused_mode() {     // 0: three kernels per layer; 1: one kernel per layer; 2 (debug): one kernel per layer, tails as separate launches
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SEEME_VAE_FUSED"); v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
+    return v;
+}
+static bool vae_fused_enabled() { return vae_fused_mode() != 0; }
+struct KvSet { unsigned short* qk; unsigned short* vt; };
+
+static int qkv_first_h(hipStream_t st, const SeemeXfLayer& L, const SeemeXfLayerH& H, const float* cur, const KvSet& kv, int B, int S, int spv) {
+    LinearHArgs q{};
+    q.k.a.A = cur; q.k.a.lda = 256; q.k.a.K1 = 256; q.k.a.K = 256; q.k.a.bias = L.in_b; q.k.a.M = B * S; q.k.a.N = 768; q.k.a.eps = 1e-5f;
+    q.wp = (const uint4*)H.in_w; q.kstride = 8; q.ntiles = 48; q.qkv_mode = 1; q.qk = kv.qk; q.vt = kv.vt; q.S = S; q.spv = spv;
+    return ((reinterpret_cast<size_t>(cur) & 15) == 0) ? launch_qkv_h(q, st) : launch_linear_h(q, st);
+}
+
+static LayerHArgs layer_args(const SeemeXfLayer& L, const SeemeXfLayerH& H, const KvSet& in, const float* res, const int32_t* lengths,
+                             int B, int S, int spv, int n_prefix, int q_rows, const float* cvec, int cvec_ld) {
+    LayerHArgs a{};
+    a.qk = in.qk; a.vt = in.vt; a.res = res; a.wo = (const uint4*)H.out_w; a.bo = L.out_b; a.n1_w = L.n1_w; a.n1_b = L.n1_b;
+    a.lengths = lengths; a.S = S; a.n_prefix = n_prefix; a.q_rows = q_rows; a.spv = spv; a.scale = 1.0f / 16.0f; a.eps = 1e-5f;
+    a.w1 = (const uint4*)H.l1_w; a.b1 = L.l1_b; a.w2 = (const uint4*)H.l2_w; a.b2 = L.l2_b; a.B = B;
+    if (cvec != nullptr) { a.cvec = cvec; a.cvec_ld = cvec_ld; a.lnc_w = L.n2_w; a.lnc_b = L.n2_b; a.n2_w = L.n3_w; a.n2_b = L.n3_b; }
+    else { a.n2_w = L.n2_w; a.n2_b = L.n2_b; }
+    return a;
+}
+static void tail_qkv(LayerHArgs& a, const SeemeXfLayer& Ln, const SeemeXfLayerH& Hn, const KvSet& out) {
+    a.qkv_w = (const uint4*)Hn.in_w; a.qkv_b = Ln.in_b; a.qk_out = out.qk; a.vt_out = out.vt;
+}
+static void tail_skip(LayerHArgs& a, const uint16_t* wp, const float* b, const float* src, float* xnext) {
+    a.skip_w = (const uint4*)wp; a.skip_b = b; a.skip_src = src; a.xnext = xnext;
+}
+
+// debug mode 2: run the layer without its tails, then the tails as the stand-alone kernels (bisecting numerical differences)
+static int launch_layer_dbg(LayerHArgs a, hipStream_t st, float* tmp_out, const SeemeXfLayer* Ln, const SeemeXfLayerH* Hn) {
+    if (vae_fused_mode() != 2 || (a.skip_w == nullptr && a.qkv_w == nullptr)) return launch_layer_h(a, st);
+    LayerHArgs b = a;
+    b.skip_w = nullptr; b.qkv_w = nullptr;
+    float* x = a.out != nullptr ? a.out : tmp_out;
+    b.out = x;
+    int rc = launch_layer_h(b, st);
+    if (rc) return rc;
+    if (a.skip_w != nullptr) {
+        if ((rc = skip_lin_h(st, x, a.skip_src, (const uint16_t*)a.skip_w, a.skip_b, a.xnext, a.B * a.S))) return rc;
+        x = a.xnext;
+    }
+    KvSet kv{a.qk_out, a.vt_out};
+    return qkv_first_h(st, *Ln, *Hn, x, kv, a.B, a.S, a.spv);
+}
+
+int seeme_vae_encode_h16(const SeemeVaeWeights* w, const float* features, const int32_t* lengths, int B, int T, float* mu,
+                         void* workspace, hipStream_t st) {
+    const SeemeVaeWeightsH* H = w->h16;
+    const int S = T + 2, F = w->nfeats;
+    WsH ws = carve_h(workspace, B, S);
+    if (!vae_fused_enabled() || ws.spv > 2 * S) return vae_encode_h16_unfused(w, features, lengths, B, T, mu, workspace, st);
+    const SeemeSkipStack& E = w->enc;
+    const KvSet kv[2] = {{ws.qk, ws.vt}, {reinterpret_cast<unsigned short*>(ws.y), ws.vt + (size_t)B * 256 * ws.spv}};
+    int rc;
+    if (vae_fused_mode() == 2) {
+        SEEME_HIP(hipMemsetAsync(ws.vt, 0, (size_t)B * 256 * ws.spv * 2 * 2, st));
+        hipLaunchKernelGGL(k_enc_tokens_h, dim3((B * 512 + 255) / 256), dim3(256), 0, st, w->token, w->pe_enc, ws.x, B, S);
+        if ((rc = seeme_check_launch("k_enc_tokens_h"))) return rc;
+        LinearHArgs ha{};
+        ha.k.a.A = features; ha.k.a.lda = F; ha.k.a.K1 = F; ha.k.a.K = F; ha.k.a.bias = w->emb_b; ha.k.a.res = w->pe_enc; ha.k.a.ldr = 256;
+        ha.k.a.Y = ws.x; ha.k.a.ldy = 256; ha.k.a.M = B * T; ha.k.a.N = 256; ha.k.a.eps = 1e-5f;
+        ha.k.seq_in = T; ha.k.in_stride = T; ha.k.out_stride = S; ha.k.out_off = 2; ha.k.res_mode = 1; ha.k.res_off = 2;
+        ha.wp = (const uint4*)H->emb_w; ha.kstride = ((F + 31) & ~31) >> 5; ha.ntiles = 16;
+        if ((rc = launch_linear_h(ha, st))) return rc;
+        if ((rc = qkv_first_h(st, E.layer[0], H->enc[0], ws.x, kv[0], B, S, ws.spv))) return rc;
+    } else {
+        ProHArgs p{};
+        p.mode = 1; p.B = B; p.S = S; p.T = T; p.F = F; p.spv = ws.spv; p.features = features; p.emb_w = (const uint4*)H->emb_w;
+        p.emb_b = w->emb_b; p.token = w->token; p.pe = w->pe_enc; p.x = ws.x;
+        p.qkv_w = (const uint4*)H->enc[0].in_w; p.qkv_b = E.layer[0].in_b; p.qk_out = kv[0].qk; p.vt_out = kv[0].vt;
+        if ((rc = launch_pro_h(p, st))) return rc;
+    }
+    LayerHArgs a = layer_args(E.layer[0], H->enc[0], kv[0], ws.x, lengths, B, S, ws.spv, 2, S, nullptr, 0);
+    a.out = ws.sk0; tail_qkv(a, E.layer[1], H->enc[1], kv[1]);
+    if ((rc = launch_layer_dbg(a, st, ws.x, &E.layer[1], &H->enc[1]))) return rc;
+    a = layer_args(E.layer[1], H->enc[1], kv[1], ws.sk0, lengths, B, S, ws.spv, 2, S, nullptr, 0);
+    a.out = ws.sk1; tail_qkv(a, E.layer[2], H->enc[2], kv[0]);
+    if ((rc = launch_layer_dbg(a, st, ws.x, &E.layer[2], &H->enc[2]))) return rc;
+    a = layer_args(E.layer[2], H->enc[2], kv[0], ws.sk1, lengths, B, S, ws.spv, 2, S, nullptr, 0);
+    tail_skip(a, H->enc_skip[0], E.skip_b[0], ws.sk1, ws.x); tail_qkv(a, E.layer[3], H->enc[3], kv[1]);
+    if ((rc = launch_layer_dbg(a, st, ws.x, &E.layer[3], &H->enc[3]))) return rc;
+    a = layer_args(E.layer[3], H->enc[3], kv[1], ws.x, lengths, B, S, ws.spv, 2, S, nullptr, 0);
+    tail_skip(a, H->enc_skip[1], E.skip_b[1], ws.sk0, ws.x); tail_qkv(a, E.layer[4], H->enc[4], kv[0]);
+    if ((rc = launch_layer_dbg(a, st, ws.x, &E.layer[4], &H->enc[4]))) return rc;
+    a = layer_args(E.layer[4], H->enc[4], kv[0], ws.x, lengths, B, S, ws.spv, 2, 2, nullptr, 0);
+    a.out = mu; a.out_mode = 1; a.fin_w = E.norm_w; a.fin_b = E.norm_b;
+    return launch_layer_h(a, st);
+}
+
+int seeme_vae_decode_h16(const SeemeVaeWeights* w, const float* z, const int32_t* lengths, int B, int T, float* feats,
+                         void* workspace, hipStream_t st) {
+    const SeemeVaeWeightsH* H = w->h16;
+    const int S = T, F = w->nfeats;
+    WsH ws = carve_h(workspace, B, S + 2);
+    ws.spv = (S + 31) & ~31;
+    if (!vae_fused_enabled() || ws.spv > 2 * S || F > 256) return vae_decode_h16_unfused(w, z, lengths, B, T, feats, workspace, st);
+    const SeemeSkipStack& Dk = w->dec;
+    const KvSet kv[2] = {{ws.qk, ws.vt}, {reinterpret_cast<unsigned short*>(ws.y), ws.vt + (size_t)B * 256 * ws.spv}};
+    int rc;
+    const int CL = SEEME_NLAYERS * 256;
+    if ((rc = lin_h(st, z, 256, H->ca_fold_w, 256, CL, w->ca_fold_b, ws.cvec, CL, B))) return rc;
+    if (vae_fused_mode() == 2) {
+        SEEME_HIP(hipMemsetAsync(ws.vt, 0, (size_t)B * 256 * ws.spv * 2 * 2, st));
+        const size_t n4 = (size_t)B * S * 64;
+        hipLaunchKernelGGL(k_bcast_rows_h, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w->pe_dec, ws.x, B, S);
+        if ((rc = seeme_check_launch("k_bcast_rows_h"))) return rc;
+        if ((rc = qkv_first_h(st, Dk.layer[0], H->dec[0], ws.x, kv[0], B, S, ws.spv))) return rc;
+    } else {
+        ProHArgs p{};
+        p.mode = 2; p.B = B; p.S = S; p.T = T; p.F = F; p.spv = ws.spv; p.pe = w->pe_dec; p.x = ws.x;
+        p.qkv_w = (const uint4*)H->dec[0].in_w; p.qkv_b = Dk.layer[0].in_b; p.qk_out = kv[0].qk; p.vt_out = kv[0].vt;
+        if ((rc = launch_pro_h(p, st))) return rc;
+    }
+    LayerHArgs a = layer_args(Dk.layer[0], H->dec[0], kv[0], ws.x, lengths, B, S, ws.spv, 0, S, ws.cvec + 0 * 256, CL);
+    a.out = ws.sk0; tail_qkv(a, Dk.layer[1], H->dec[1], kv[1]);
+    if ((rc = launch_layer_dbg(a, st, ws.x, &Dk.layer[1], &H->dec[1]))) return rc;
+    a = layer_args(Dk.layer[1], H->dec[1], kv[1], ws.sk0, lengths, B, S, ws.spv, 0, S, ws.cvec + 1 * 256, CL);
+    a.out = ws.sk1; tail_qkv(a, Dk.layer[2], H->dec[2], kv[0]);
+    if ((rc = launch_layer_dbg(a, st, ws.x, &Dk.layer[2], &H->dec[2]))) return rc;
+    a = layer_args(Dk.layer[2], H->dec[2], kv[0], ws.sk1, lengths, B, S, ws.spv, 0, S, ws.cvec + 2 * 256, CL);
+    tail_skip(a, H->dec_skip[0], Dk.skip_b[0], ws.sk1, ws.x); tail_qkv(a, Dk.layer[3], H->dec[3], kv[1]);
+    if ((rc = launch_layer_dbg(a, st, ws.x, &Dk.layer[3], &H->dec[3]))) return rc;
+    a = layer_args(Dk.layer[3], H->dec[3], kv[1], ws.x, lengths, B, S, ws.spv, 0, S, ws.cvec + 3 * 256, CL);
+    tail_skip(a, H->dec_skip[1], Dk.skip_b[1], ws.sk0, ws.x); tail_qkv(a, Dk.layer[4], H->dec[4], kv[0]);
+    if ((rc = launch_layer_dbg(a, st, ws.x, &Dk.layer[4], &H->dec[4]))) return rc;
+    a = layer_args(Dk.layer[4], H->dec[4], kv[0], ws.x, lengths, B, S, ws.spv, 0, S, ws.cvec + 4 * 256, CL);
+    a.fin_w = Dk.norm_w; a.fin_b = Dk.norm_b; a.proj_w = (const uint4*)H->fin_w; a.proj_b = w->fin_b; a.feats = feats; a.F = F;
+    return launch_layer_h(a, st);
 }
