@@ -362,7 +362,8 @@ int seeme_glue_ln(const float* x, float* xhat, float* rstd, int M, void* stream)
 
 /* One problem of seeme_grouped_gemm:  C[i,j] (+)= sum_s sum_{k < seg_len[s]} A_s[i,k] * B_s[k,j]  (+ bias[j]) (* epilogue)
  * with A_s[i,k] = pro_a(a[s][i*a_rs + k*a_ks[s]]) and B_s[k,j] = pro_b(b[s][k*b_ks[s] + j*b_cs]); prologue modes: 0 none, 1 SiLU,
- * 2 ReLU, 3 affine v*p0[idx] + p1[idx] (idx = k for A, j for B).  epi 1: multiply by SiLU'(e0[i*e_ld + j]).  colsum (needs
+ * 2 ReLU, 3 affine v*p0[idx] + p1[idx] (idx = k for A, j for B).  epi 1: multiply by SiLU'(e0[i*e_ld + j]); epi 2: by alpha.
+ * colsum (needs
  * a_rs == 1): colsum[i] (+)= sum_s sum_k a[s][i,k] -- the bias gradient that comes free with a weight gradient.  tile0 /
  * tiles_n: position of the problem's 64x64 tiles in the launch. */
 typedef struct {
@@ -389,7 +390,12 @@ typedef struct {
     int accumulate;
     float* colsum;
     int tile0, tiles_n;
-} SeemeGemmProblem;
+    int nbatch;               /* > 1: nbatch independent problems of this shape; a[s] / b[s] / c advance by the strides below */
+    long a_bstride, b_bstride, c_bstride;
+    float alpha;              /* epi 2: C = alpha * (A B + bias) */
+    const float* addend;      /* optional [M,N] (row stride add_ld) added after the epilogue */
+    long add_ld;
+} SeemeGemmProblem;              /* accumulate: 0 store, 1 C += (one writer), 2 atomicAdd (nbatch members share C: split reduction) */
 int seeme_grouped_gemm(const SeemeGemmProblem* probs_dev, int n_probs, int n_tiles, void* stream);
 int seeme_gemm_problem_bytes(void);
 
@@ -411,6 +417,34 @@ typedef struct {
     float* demb;              /* [B,256] */
 } SeemeGlueMid;
 int seeme_glue_mid(const SeemeGlueMid* a, void* stream);
+
+/* ------------------------------------------------------------------ stage-1 (VAE) training: row kernels
+ * The hand-written forward-with-saves / backward of MldVae.encode / decode for train_vae_forward (mld.py:633-885; layers
+ * cross_attention.py:41-147,281-367).  GEMMs run on seeme_grouped_gemm; call order in seeme_amd/vae_train.py. */
+typedef struct {
+    const float* sub;         /* [M,256] sublayer output, or one row per sequence when sub_seq_rows > 0 */
+    const float* res;         /* [M,256] residual or NULL */
+    const float* gamma; const float* beta;
+    float* y; float* xhat; float* rstd;
+    long M; int sub_seq_rows; float eps;
+} SeemeVtLn;
+int seeme_vt_add_ln(const SeemeVtLn* a, void* stream);        /* y = LN(sub + res); keeps xhat, rstd */
+typedef struct {
+    const float* dy; const float* xhat; const float* rstd; const float* gamma;
+    float* dpre;              /* [M,256] gradient w.r.t. (sub + res) */
+    float* dgamma; float* dbeta;   /* accumulated (atomics) */
+    long M; int accumulate;   /* 1: dpre += */
+    const float* dy2;         /* optional second gradient of the same output (skip connection): dy + dy2 */
+} SeemeVtLnBwd;
+int seeme_vt_ln_bwd(const SeemeVtLnBwd* a, void* stream);
+/* scores [B,S,S] = q k^T (unscaled) -> softmax(scale * s) over the keys [0, min(S, n_prefix + lengths[b])), zeros elsewhere. */
+int seeme_vt_softmax_fwd(float* scores, const int32_t* lengths, int B, int S, int n_prefix, float scale, void* stream);
+/* dp [rows,S] (gradient w.r.t. the probabilities) -> gradient w.r.t. the unscaled scores, in place. */
+int seeme_vt_softmax_bwd(float* dp, const float* p, long rows, int S, float scale, void* stream);
+/* exact GELU: dh == NULL: out = gelu(pre); else out = dh * gelu'(pre). */
+int seeme_vt_gelu(const float* pre, const float* dh, float* out, long n, void* stream);
+/* out[b,:] (+)= sum_s d[b,s,:]  (d [B,S,256]). */
+int seeme_vt_seq_sum(const float* d, float* out, int B, int S, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@ root="$(cd "$(dirname "$0")/.." && pwd)"
 out="$root/probes/variants"; mkdir -p "$out"
 src="$root/seeme_amd/csrc"
 objs=()
-for f in api vae_kernels den_kernels misc_kernels pointnet_bf16 vae_h16 smpl_kernels glue_kernels; do
+for f in api vae_kernels den_kernels misc_kernels pointnet_bf16 vae_h16 smpl_kernels glue_kernels vae_train; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wno-unused-function -o "$out/$f.o" "$src/$f.hip" &
   objs+=("$out/$f.o")
 done

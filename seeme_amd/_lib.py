@@ -113,7 +113,19 @@ class GemmProblem(C.Structure):
                 ("b_ks", C.c_long * 10), ("nseg", C.c_int), ("a_rs", C.c_long), ("b_cs", C.c_long), ("c", fp), ("ldc", C.c_long),
                 ("M", C.c_int), ("N", C.c_int), ("a_pro", C.c_int), ("a_p0", fp), ("a_p1", fp), ("b_pro", C.c_int),
                 ("b_p0", fp), ("b_p1", fp), ("bias", fp), ("epi", C.c_int), ("e0", fp), ("e_ld", C.c_long),
-                ("accumulate", C.c_int), ("colsum", fp), ("tile0", C.c_int), ("tiles_n", C.c_int)]
+                ("accumulate", C.c_int), ("colsum", fp), ("tile0", C.c_int), ("tiles_n", C.c_int), ("nbatch", C.c_int),
+                ("a_bstride", C.c_long), ("b_bstride", C.c_long), ("c_bstride", C.c_long), ("alpha", C.c_float), ("addend", fp),
+                ("add_ld", C.c_long)]
+
+
+class VtLn(C.Structure):
+    _fields_ = [("sub", fp), ("res", fp), ("gamma", fp), ("beta", fp), ("y", fp), ("xhat", fp), ("rstd", fp), ("M", C.c_long),
+                ("sub_seq_rows", C.c_int), ("eps", C.c_float)]
+
+
+class VtLnBwd(C.Structure):
+    _fields_ = [("dy", fp), ("xhat", fp), ("rstd", fp), ("gamma", fp), ("dpre", fp), ("dgamma", fp), ("dbeta", fp), ("M", C.c_long),
+                ("accumulate", C.c_int), ("dy2", fp)]
 
 
 class GlueMid(C.Structure):
@@ -125,6 +137,12 @@ GEO_AA_TO_QUAT, GEO_AA_TO_ROTMAT, GEO_QUAT_TO_ROTMAT, GEO_ROT6D_PROHMR, GEO_ROT6
 
 # name -> (restype, argtypes); every symbol of include/seeme_hip.h
 _SIGNATURES = {
+    "seeme_vt_add_ln": (C.c_int, [C.POINTER(VtLn), fp]),
+    "seeme_vt_ln_bwd": (C.c_int, [C.POINTER(VtLnBwd), fp]),
+    "seeme_vt_softmax_fwd": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, fp]),
+    "seeme_vt_softmax_bwd": (C.c_int, [fp, fp, C.c_long, C.c_int, C.c_float, fp]),
+    "seeme_vt_gelu": (C.c_int, [fp, fp, fp, C.c_long, fp]),
+    "seeme_vt_seq_sum": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, fp]),
     "seeme_den_vecgrad": (C.c_int, [fp, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, fp, fp]),
     "seeme_glue_rows": (C.c_int, [C.POINTER(GlueRows), fp]),
     "seeme_glue_ln": (C.c_int, [fp, fp, fp, C.c_int, fp]),

@@ -3,7 +3,7 @@
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
 out="$here/../libseeme_hip.so"
-srcs=("$here"/api.hip "$here"/vae_kernels.hip "$here"/den_kernels.hip "$here"/misc_kernels.hip "$here"/pointnet_bf16.hip "$here"/pointnet_v2.hip "$here"/vae_h16.hip "$here"/glue_kernels.hip)
+srcs=("$here"/api.hip "$here"/vae_kernels.hip "$here"/den_kernels.hip "$here"/misc_kernels.hip "$here"/pointnet_bf16.hip "$here"/pointnet_v2.hip "$here"/vae_h16.hip "$here"/glue_kernels.hip "$here"/vae_train.hip)
 [ -f "$here/smpl_kernels.hip" ] && srcs+=("$here/smpl_kernels.hip")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
     -Wall -Wno-unused-function -o "$out" "${srcs[@]}" "$@"

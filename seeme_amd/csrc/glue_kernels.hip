@@ -121,14 +121,21 @@ __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__
     __shared__ float cs[4][GG_T];
     __shared__ int s_prob;
     const int t = threadIdx.x;
-    if (t == 0) {
-        int p = 0;
-        while (p + 1 < n_probs && (int)blockIdx.x >= probs[p + 1].tile0) ++p;
-        s_prob = p;
+    if (t == 0) {                       // last problem whose first tile is <= blockIdx.x (tile0 is ascending)
+        int lo = 0, hi = n_probs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((int)blockIdx.x >= probs[mid].tile0) lo = mid; else hi = mid - 1;
+        }
+        s_prob = lo;
     }
     __syncthreads();
     const SeemeGemmProblem& P = probs[s_prob];
-    const int tile = blockIdx.x - P.tile0;
+    int tile = blockIdx.x - P.tile0;
+    const int tiles_1 = P.tiles_n * ((P.M + GG_T - 1) / GG_T);      // tiles of one batch member
+    const int bz = P.nbatch > 1 ? tile / tiles_1 : 0;
+    tile -= bz * tiles_1;
+    const long a_boff = (long)bz * P.a_bstride, b_boff = (long)bz * P.b_bstride, c_boff = (long)bz * P.c_bstride;
     const int i0 = (tile / P.tiles_n) * GG_T, j0 = (tile % P.tiles_n) * GG_T;
     const int M = P.M, N = P.N, nseg = P.nseg, a_pro = P.a_pro, b_pro = P.b_pro;
     const long a_rs = P.a_rs, b_cs = P.b_cs;
@@ -147,8 +154,8 @@ __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__
     auto fetch = [&]() {
         // (pointers read from the descriptor are generic: cast to the global address space, or every access is a FLAT load
         // that the compiler waits for one at a time)
-        const gfloat* ap = (const gfloat*)P.a[seg];
-        const gfloat* bp = (const gfloat*)P.b[seg];
+        const gfloat* ap = (const gfloat*)P.a[seg] + a_boff;
+        const gfloat* bp = (const gfloat*)P.b[seg] + b_boff;
         const int len = P.seg_len[seg];
         const long aks = P.a_ks[seg], bks = P.b_ks[seg];
 #pragma unroll
@@ -251,8 +258,11 @@ __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__
             float v = acc[x][y];
             if (P.bias) v += P.bias[j];
             if (P.epi == 1) v *= dsilu_f(P.e0[(long)i * P.e_ld + j]);
-            float* dst = P.c + (long)i * P.ldc + j;
-            *dst = P.accumulate ? *dst + v : v;
+            else if (P.epi == 2) v *= P.alpha;
+            if (P.addend) v += P.addend[(long)i * P.add_ld + j];
+            float* dst = P.c + c_boff + (long)i * P.ldc + j;
+            if (P.accumulate == 2) atomicAdd(dst, v);          // split reductions (nbatch members sharing one C)
+            else *dst = P.accumulate ? *dst + v : v;
         }
     }
     if (want_cs) {
@@ -260,7 +270,8 @@ __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__
         __syncthreads();
         if (t < GG_T && i0 + t < M) {
             const float v = cs[0][t] + cs[1][t] + cs[2][t] + cs[3][t];
-            P.colsum[i0 + t] = P.accumulate ? P.colsum[i0 + t] + v : v;
+            if (P.accumulate == 2) atomicAdd(P.colsum + i0 + t, v);
+            else P.colsum[i0 + t] = P.accumulate ? P.colsum[i0 + t] + v : v;
         }
     }
 }

@@ -268,6 +268,7 @@ class MLD(nn.Module):
         if self.cfg_scene_order not in ("reference", "fixed"):
             raise ValueError("TEST.CFG_SCENE_ORDER must be 'reference' or 'fixed'")
         self.hip_backward = cfg.TRAIN.get("HIP_BACKWARD", True)   # hand-written backward of the denoiser chain (one head)
+        self.hip_vae_backward = cfg.TRAIN.get("HIP_VAE_BACKWARD", True)   # stage 1: hand-written VAE backward (vae_train.py)
         self.hip_glue = cfg.TRAIN.get("HIP_GLUE", True)           # ... and of everything around it (stage2_glue.py); needs HIP_BACKWARD
         self.pose_estimation_task = cfg.TEST.get("POSE_ESTIMATION_TASK", False)      # mld.py:116
         if self.name_dataset == "egobody":                               # mld.py:122-125
@@ -476,6 +477,19 @@ class MLD(nn.Module):
             raise ValueError("no condition: MldDenoiser needs at least one condition token")
         return {**self._diffusion_process(z, cond_emb, lengths, noise=noise, timesteps=timesteps)}
 
+    def _vae_trainer(self, T: int):
+        """The hand-written stage-1 forward / backward (vae_train.VaeTrainer) when this model can take it."""
+        if not self.hip_vae_backward:
+            return None
+        from .vae_train import VaeTrainer
+        if not VaeTrainer.supported(self.vae, T):
+            return None
+        t = getattr(self, "_vae_tr", None)
+        if t is None or t.stale():
+            t = VaeTrainer(self.vae)
+            object.__setattr__(self, "_vae_tr", t)
+        return t
+
     def _stage2_glue(self, n_tokens: int):
         """The hand-written forward/backward around the chain (stage2_glue.Stage2Glue) when this step can take it."""
         if not (self.hip_glue and self.hip_backward and torch.is_grad_enabled() and n_tokens >= 1):
@@ -533,11 +547,18 @@ class MLD(nn.Module):
         ref_orient = m_ref[:, :, :3] if gimo else None
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.vae.parameters()):
             # stage-1 training: differentiable twins of the VAE and the SMPL joint regressor (PyTorch-ROCm autograd)
-            from .vae_autograd import vae_encode_torch, vae_decode_torch
-            mu, std = vae_encode_torch(self.vae, f_ref, lengths)
+            tr = self._vae_trainer(f_ref.shape[1]) if f_ref.is_cuda else None
+            if tr is not None:        # hand-written HIP forward-with-saves / backward of the encoder and the decoder (vae_train.py)
+                mu, logvar = tr.encode(f_ref, lengths)
+                std = logvar.exp().pow(0.5)
+                dec = tr.decode
+            else:                     # differentiable twins on PyTorch autograd
+                from .vae_autograd import vae_encode_torch, vae_decode_torch
+                mu, std = vae_encode_torch(self.vae, f_ref, lengths)
+                dec = lambda zz, ll: vae_decode_torch(self.vae, zz, ll)
             dist_m = torch.distributions.Normal(mu, std, validate_args=False)
             z = dist_m.rsample() if eps is None else mu + eps.to(mu) * std
-            m_rst = self.renorm(vae_decode_torch(self.vae, z, lengths))    # differentiable (geometry._Renorm)
+            m_rst = self.renorm(dec(z, lengths))                           # differentiable (geometry._Renorm)
             with torch.no_grad():
                 joints_ref = self._feats_to_joints(m_ref, beta[:, idx])[:, :, :nj]
             joints_rst = self._feats_to_joints_torch(m_rst, beta[:, idx], orient=ref_orient)[:, :, :nj]

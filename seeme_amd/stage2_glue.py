@@ -37,6 +37,7 @@ class _Group:
         t0 = 0
         for p in probs:
             n, tn = _tiles(p.M, p.N)
+            n *= max(1, p.nbatch)
             p.tile0, p.tiles_n = t0, tn
             if p.colsum and (p.a_rs != 1 or p.a_pro):
                 raise ValueError("colsum needs an i-contiguous A without a prologue")
@@ -52,7 +53,7 @@ class _Group:
 
 
 def _prob(a, b, seg_len, a_ks, b_ks, a_rs, b_cs, c, ldc, M, N, *, a_pro=0, a_p=(0, 0), b_pro=0, b_p=(0, 0), bias=0, epi=0,
-          e0=0, e_ld=0, accumulate=0, colsum=0) -> L.GemmProblem:
+          e0=0, e_ld=0, accumulate=0, colsum=0, nbatch=1, bstrides=(0, 0, 0), alpha=1.0, addend=0, add_ld=0) -> L.GemmProblem:
     p = L.GemmProblem()
     n = len(a)
     for s in range(n):
@@ -60,6 +61,8 @@ def _prob(a, b, seg_len, a_ks, b_ks, a_rs, b_cs, c, ldc, M, N, *, a_pro=0, a_p=(
     p.nseg, p.a_rs, p.b_cs, p.c, p.ldc, p.M, p.N = n, a_rs, b_cs, c, ldc, M, N
     p.a_pro, p.a_p0, p.a_p1, p.b_pro, p.b_p0, p.b_p1 = a_pro, a_p[0], a_p[1], b_pro, b_p[0], b_p[1]
     p.bias, p.epi, p.e0, p.e_ld, p.accumulate, p.colsum = bias, epi, e0, e_ld, accumulate, colsum
+    p.nbatch, p.a_bstride, p.b_bstride, p.c_bstride, p.alpha = nbatch, bstrides[0], bstrides[1], bstrides[2], alpha
+    p.addend, p.add_ld = addend, add_ld
     return p
 
 
