@@ -250,6 +250,12 @@ int seeme_smpl_lbs(const SeemeSmplModel* m, const float* betas, const float* pos
                    const float* transl, int M, float* joints, float* vertices,
                    void* workspace, size_t ws_bytes, void* stream);
 
+/* Gradient of the 24 posed joints (the first 24 of seeme_smpl_lbs's joints, axis-angle pose) w.r.t. pose [M,72] and transl
+ * [M,3] (dtransl may be NULL): djoints [M, dj_stride >= 24, 3].  Replaces autograd through smplx's lbs for the joints loss of
+ * train_vae_forward (mld.py:764-773,871-878). */
+int seeme_smpl_joints_backward(const SeemeSmplModel* m, const float* betas, const float* pose, const float* djoints, int dj_stride,
+                               float* dpose, float* dtransl, int M, void* stream);
+
 /* ------------------------------------------------------------------ rotation helpers / renorm
  * mld/utils/geometry2.py: aa_to_quat :33-54, aa_to_rotmat :56-72, quat_to_rotmat :74-95,
  * rot6d_to_rotmat :98-117 ('prohmr' / 'diffusion' column order).  in [M,3|4|6] -> out [M,4] or [M,3,3]. */

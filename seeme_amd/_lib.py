@@ -137,6 +137,7 @@ GEO_AA_TO_QUAT, GEO_AA_TO_ROTMAT, GEO_QUAT_TO_ROTMAT, GEO_ROT6D_PROHMR, GEO_ROT6
 
 # name -> (restype, argtypes); every symbol of include/seeme_hip.h
 _SIGNATURES = {
+    "seeme_smpl_joints_backward": (C.c_int, [C.POINTER(SmplModel), fp, fp, fp, C.c_int, fp, fp, C.c_int, fp]),
     "seeme_vt_add_ln": (C.c_int, [C.POINTER(VtLn), fp]),
     "seeme_vt_ln_bwd": (C.c_int, [C.POINTER(VtLnBwd), fp]),
     "seeme_vt_softmax_fwd": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, fp]),

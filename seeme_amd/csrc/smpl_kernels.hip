@@ -219,3 +219,135 @@ extern "C" int seeme_smpl_lbs(const SeemeSmplModel* model, const float* betas, c
                        vertices, model->V, nvb);
     return seeme_check_launch("k_smpl_skin");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the 24 posed joints w.r.t. the axis-angle pose and the translation (stage-1 training: the joints loss of
+// train_vae_forward, mld.py:764-773,871-878, goes through smplx's lbs).  One wave per frame, lanes <-> joints:
+//   forward again (Rodrigues, rest joints, world rotations W_j = W_parent R_j), then
+//   p_j = p_parent + W_parent rel_j  gives, walking the tree from the leaves (one lane, 23 steps):
+//     g_p[parent] += g_p[j];  g_W[parent] += g_p[j] rel_j^T + g_W[j] R_j^T;  g_R[j] = W_parent^T g_W[j]
+//   and every lane turns its g_R into the gradient of its axis-angle vector through d(Rodrigues)/d(aa).
+__global__ __launch_bounds__(256) void k_smpl_joints_bwd(const SeemeSmplModel m, const float* __restrict__ betas,
+                                                         const float* __restrict__ pose, const float* __restrict__ djoints,
+                                                         int dj_stride, float* __restrict__ dpose, float* __restrict__ dtransl, int M) {
+    __shared__ float sR[4][SMPL_J][9], sW[4][SMPL_J][9], sJ[4][SMPL_J][3], sRel[4][SMPL_J][3];
+    __shared__ float sGp[4][SMPL_J][3], sGW[4][SMPL_J][9], sGR[4][SMPL_J][9];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int mraw = blockIdx.x * 4 + wave;
+    const bool live = mraw < M;
+    const int f = live ? mraw : M - 1;
+    const float* beta = betas + (size_t)f * 10;
+    float aa[3] = {0.f, 0.f, 0.f};
+    if (lane < SMPL_J) {
+        const float* r = pose + ((size_t)f * SMPL_J + lane) * 3;
+        aa[0] = r[0]; aa[1] = r[1]; aa[2] = r[2];
+        const float ex = aa[0] + 1e-8f, ey = aa[1] + 1e-8f, ez = aa[2] + 1e-8f;
+        const float ang = sqrtf(ex * ex + ey * ey + ez * ez);
+        const float dx = aa[0] / ang, dy = aa[1] / ang, dz = aa[2] / ang;
+        const float s = sinf(ang), c1 = 1.f - cosf(ang);
+        const float K[9] = {0.f, -dz, dy, dz, 0.f, -dx, -dy, dx, 0.f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float kk = K[i * 3 + 0] * K[0 * 3 + j] + K[i * 3 + 1] * K[1 * 3 + j] + K[i * 3 + 2] * K[2 * 3 + j];
+                sR[wave][lane][i * 3 + j] = (i == j ? 1.f : 0.f) + s * K[i * 3 + j] + c1 * kk;
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = m.J_template[lane * 3 + c];
+#pragma unroll
+            for (int l = 0; l < 10; ++l) v = fmaf(m.J_shapedirs[(lane * 3 + c) * 10 + l], beta[l], v);
+            sJ[wave][lane][c] = v;
+            sGp[wave][lane][c] = djoints[((size_t)f * dj_stride + lane) * 3 + c];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sGW[wave][lane][i] = 0.f;
+    }
+    __syncthreads();
+    if (lane < SMPL_J) {
+        const int p = m.parents[lane];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sRel[wave][lane][c] = sJ[wave][lane][c] - (p >= 0 ? sJ[wave][p][c] : 0.f);
+        // world rotation: W_j = R_root ... R_parent R_j (leaf-to-root accumulation, as the forward kernel)
+        float W[9], N2[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) W[i] = sR[wave][lane][i];
+        int q = p;
+        for (int hop = 0; hop < SMPL_J && q >= 0; ++hop) {
+            const float* Rq = &sR[wave][q][0];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) N2[i * 3 + j] = Rq[i * 3 + 0] * W[0 * 3 + j] + Rq[i * 3 + 1] * W[1 * 3 + j] + Rq[i * 3 + 2] * W[2 * 3 + j];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) W[i] = N2[i];
+            q = m.parents[q];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sW[wave][lane][i] = W[i];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float tsum[3] = {0.f, 0.f, 0.f};
+        for (int j = 0; j < SMPL_J; ++j)
+            for (int c = 0; c < 3; ++c) tsum[c] += sGp[wave][j][c];
+        if (live && dtransl != nullptr)
+            for (int c = 0; c < 3; ++c) dtransl[(size_t)f * 3 + c] = tsum[c];
+        for (int j = SMPL_J - 1; j >= 1; --j) {
+            const int p = m.parents[j];
+            const float* gp = &sGp[wave][j][0];
+            const float* gW = &sGW[wave][j][0];
+            const float* Rj = &sR[wave][j][0];
+            const float* Wp = &sW[wave][p][0];
+            for (int a = 0; a < 3; ++a) {
+                sGp[wave][p][a] += gp[a];
+                for (int b = 0; b < 3; ++b) {
+                    // g_W[p] += g_p[j] rel_j^T + g_W[j] R_j^T ;  g_R[j] = W_p^T g_W[j]
+                    sGW[wave][p][a * 3 + b] += gp[a] * sRel[wave][j][b] + gW[a * 3 + 0] * Rj[b * 3 + 0] + gW[a * 3 + 1] * Rj[b * 3 + 1] + gW[a * 3 + 2] * Rj[b * 3 + 2];
+                    sGR[wave][j][a * 3 + b] = Wp[0 * 3 + a] * gW[0 * 3 + b] + Wp[1 * 3 + a] * gW[1 * 3 + b] + Wp[2 * 3 + a] * gW[2 * 3 + b];
+                }
+            }
+        }
+        for (int i = 0; i < 9; ++i) sGR[wave][0][i] = sGW[wave][0][i];
+    }
+    __syncthreads();
+    if (live && lane < SMPL_J) {
+        const float* g = &sGR[wave][lane][0];
+        const float e[3] = {aa[0] + 1e-8f, aa[1] + 1e-8f, aa[2] + 1e-8f};
+        const float th = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        const float d[3] = {aa[0] / th, aa[1] / th, aa[2] / th};
+        const float s = sinf(th), c = cosf(th), c1 = 1.f - c;
+        const float dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        const float tr = g[0] + g[4] + g[8];
+        const float w[3] = {g[7] - g[5], g[2] - g[6], g[3] - g[1]};                       // sum(gR o K(v)) = v . w
+        float Gd[3], Gtd[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            Gd[a] = g[a * 3 + 0] * d[0] + g[a * 3 + 1] * d[1] + g[a * 3 + 2] * d[2];
+            Gtd[a] = g[0 * 3 + a] * d[0] + g[1 * 3 + a] * d[1] + g[2 * 3 + a] * d[2];
+        }
+        const float dGd = d[0] * Gd[0] + d[1] * Gd[1] + d[2] * Gd[2];
+        const float dw = d[0] * w[0] + d[1] * w[1] + d[2] * w[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float thk = e[k] / th;
+            float pd[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pd[j] = ((j == k ? 1.f : 0.f) - d[j] * thk) / th;
+            const float pdw = pd[0] * w[0] + pd[1] * w[1] + pd[2] * w[2];
+            const float pdGd = pd[0] * Gd[0] + pd[1] * Gd[1] + pd[2] * Gd[2];
+            const float Gtdpd = Gtd[0] * pd[0] + Gtd[1] * pd[1] + Gtd[2] * pd[2];
+            const float dpd = d[0] * pd[0] + d[1] * pd[1] + d[2] * pd[2];
+            dpose[((size_t)f * SMPL_J + lane) * 3 + k] = c * thk * dw + s * pdw + s * thk * (dGd - dd * tr) + c1 * (pdGd + Gtdpd - 2.f * dpd * tr);
+        }
+    }
+}
+
+extern "C" int seeme_smpl_joints_backward(const SeemeSmplModel* model, const float* betas, const float* pose, const float* djoints,
+                                          int dj_stride, float* dpose, float* dtransl, int M, void* stream) {
+    if (!model || !betas || !pose || !djoints || !dpose || M <= 0 || dj_stride < SMPL_J) return seeme_fail("smpl_joints_backward: bad arguments");
+    hipLaunchKernelGGL(k_smpl_joints_bwd, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *model, betas, pose, djoints, dj_stride,
+                       dpose, dtransl, M);
+    return seeme_check_launch("k_smpl_joints_bwd");
+}

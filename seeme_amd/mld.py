@@ -613,6 +613,9 @@ class MLD(nn.Module):
         if nb < 69:                                                        # GIMO pads 21 -> 23 joints (mld.py:807-813)
             pose = torch.cat([pose, torch.zeros(B * T, 69 - nb, device=pose.device, dtype=pose.dtype)], dim=1)
         tr = feats[:, :, -3:].reshape(B * T, 3) if self.predict_transl else None
+        if self.hip_vae_backward and pose.is_cuda:           # HIP forward + hand-written backward (smpl._JointsAA)
+            from .smpl import smpl_joints_hip
+            return smpl_joints_hip(self.smpl_model, betas.reshape(-1, 10).float(), pose.float(), tr).reshape(B, T, 24, 3)
         return smpl_joints_torch(self.smpl_model, betas.reshape(-1, 10).float(), pose.float(), tr).reshape(B, T, 24, 3)
 
     # ------------------------------------------------------------------ evaluation (mld.py:1076-1905, live part)

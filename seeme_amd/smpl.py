@@ -221,3 +221,41 @@ class SMPL(nn.Module):
         L.check(rc, "seeme_smpl_lbs")
         return SimpleNamespace(vertices=verts, joints=joints, betas=betas, body_pose=body_pose,
                                global_orient=global_orient, full_pose=pose if return_full_pose else None)
+
+
+class _JointsAA(torch.autograd.Function):
+    """The 24 posed joints as a differentiable function of the axis-angle pose [M,72] and the translation [M,3]: forward =
+    the joints-only launch of ``seeme_smpl_lbs``, backward = ``seeme_smpl_joints_backward`` (hand-written; replaces autograd
+    through smplx's lbs for the joints loss of ``train_vae_forward``, mld.py:764-773,871-878).  betas get no gradient."""
+
+    @staticmethod
+    def forward(ctx, smpl, betas, pose, transl):
+        M = pose.shape[0]
+        pose = pose.to(torch.float32).contiguous()
+        betas = betas.to(torch.float32).contiguous()
+        tr = None if transl is None else transl.to(torch.float32).contiguous()
+        joints = torch.empty(M, 45, 3, device=pose.device, dtype=torch.float32)
+        model = smpl._model()
+        L.check(L.lib().seeme_smpl_lbs(C.byref(model), betas.data_ptr(), pose.data_ptr(), 0, L.ptr(tr), M, joints.data_ptr(), 0, 0, 0,
+                                       L.current_stream()), "seeme_smpl_lbs")
+        ctx.smpl, ctx.has_tr = smpl, tr is not None
+        ctx.save_for_backward(betas, pose)
+        return joints[:, :24]
+
+    @staticmethod
+    def backward(ctx, dj):
+        betas, pose = ctx.saved_tensors
+        M = pose.shape[0]
+        dj = dj.to(torch.float32).contiguous()
+        dpose = torch.empty_like(pose)
+        dtr = torch.empty(M, 3, device=pose.device, dtype=torch.float32) if ctx.has_tr else None
+        model = ctx.smpl._model()
+        L.check(L.lib().seeme_smpl_joints_backward(C.byref(model), betas.data_ptr(), pose.data_ptr(), dj.data_ptr(), 24, dpose.data_ptr(),
+                                                    L.ptr(dtr), M, L.current_stream()), "seeme_smpl_joints_backward")
+        return None, None, dpose, dtr
+
+
+def smpl_joints_hip(smpl, betas: torch.Tensor, pose_aa: torch.Tensor, transl: torch.Tensor = None) -> torch.Tensor:
+    """[M,24,3] posed joints, differentiable w.r.t. pose_aa [M,72] and transl [M,3] (HIP forward and backward)."""
+    L.require_cuda(pose_aa, "pose_aa")
+    return _JointsAA.apply(smpl, betas, pose_aa, transl)

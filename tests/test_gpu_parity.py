@@ -865,3 +865,32 @@ def test_vae_autograd_twin_matches_hip_and_stage1_trains(dev):
     # pinned against the oracle in tests/test_gpu_flows.py) falling slowest
     assert all(np.isfinite(losses)) and losses[-1] < 0.985 * losses[0] and np.mean(losses[-10:]) < np.mean(losses[:10]), losses
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in model.vae.named_parameters() if "query_pos" not in n)
+
+
+def test_smpl_joints_backward_matches_autograd(dev):
+    """seeme_smpl_joints_backward (hand-written: world rotations, leaf-to-root accumulation, d Rodrigues / d axis-angle) against
+    autograd through the PyTorch twin of smplx's lbs (vae_autograd.smpl_joints_torch): forward joints and the gradients w.r.t.
+    pose and translation for random poses, a zero pose (the 1e-8 regularised angle) and a padded (GIMO-style) pose."""
+    from seeme_amd.smpl import SMPL, smpl_joints_hip
+    from seeme_amd.vae_autograd import smpl_joints_torch
+    smpl = SMPL.synthetic(1234).to(dev)
+    g = torch.Generator().manual_seed(8)
+    M = 37
+    betas = (torch.randn(M, 10, generator=g) * 0.5).to(dev)
+    pose = (torch.randn(M, 72, generator=g) * 0.5).to(dev)
+    pose[3] = 0.0
+    pose[5, 66:] = 0.0
+    tr = torch.randn(M, 3, generator=g).to(dev)
+    wgt = torch.randn(M, 24, 3, generator=g).to(dev)
+    res = []
+    for fn in (smpl_joints_hip, smpl_joints_torch):
+        p, t = pose.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+        j = fn(smpl, betas, p, t)
+        (j * wgt).sum().backward()
+        res.append((j.detach(), p.grad.clone(), t.grad.clone()))
+    assert rel_err(res[0][0].cpu().numpy(), res[1][0].cpu().numpy()) < TOL_F32
+    assert rel_err(res[0][1].cpu().numpy(), res[1][1].cpu().numpy()) < 1e-4
+    assert rel_err(res[0][2].cpu().numpy(), res[1][2].cpu().numpy()) < 1e-5
+    p = pose.clone().requires_grad_(True)                   # without a translation
+    smpl_joints_hip(smpl, betas, p, None).mul(wgt).sum().backward()
+    assert rel_err(p.grad.cpu().numpy(), res[1][1].cpu().numpy()) < 1e-4
