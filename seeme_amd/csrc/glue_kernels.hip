@@ -107,6 +107,9 @@ __global__ __launch_bounds__(256) void k_glue_mid(SeemeGlueMid a) {
 
 // ------------------------------------------------------------------ grouped GEMM
 #define GG_T 64
+#ifndef GG_MFMA
+#define GG_MFMA 1
+#endif
 #ifndef GG_K
 #define GG_K 64          // k-step: 16 loads of A and 16 of B in flight per thread -- the weights are cold in HBM every step
 #endif                   // (PointNet streams GBs in between), so the tile time is round trips, not FLOPs
@@ -209,6 +212,55 @@ __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__
             Bs[kb][b_j(e)] = okb ? rb[e] : 0.f;
         }
     };
+#if GG_MFMA
+    // inner product on the matrix cores: v_mfma_f32_32x32x2_f32 is an fp32 FMA chain (same arithmetic as the vector-ALU loop it
+    // replaces) that costs one issue slot per 4096 FLOPs instead of one per 256 -- the vector ALU is left to the staging code.
+    // Wave (wi, wj) owns the 32 x 32 quadrant; a lane supplies A[i = lane % 32][k + lane / 32] and B[k + lane / 32][j = lane % 32].
+    typedef float gg_f32x16 __attribute__((ext_vector_type(16)));
+    gg_f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    const int wv = t >> 6, ln = t & 63, wi = wv >> 1, wj = wv & 1;
+    const float* ap0 = &As[ln >> 5][32 * wi + (ln & 31)];
+    const float* bp0 = &Bs[ln >> 5][32 * wj + (ln & 31)];
+    fetch();
+    while (seg < nseg) {
+        stage(k0, P.seg_len[seg]);
+        __syncthreads();
+        k0 += GG_K;
+        if (k0 >= P.seg_len[seg]) { k0 = 0; ++seg; }
+        if (seg < nseg) fetch();
+        float fa[2][8], fb[2][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { fa[0][q] = ap0[2 * q * GG_LD]; fb[0][q] = bp0[2 * q * GG_LD]; }
+#pragma unroll
+        for (int c = 0; c < GG_K / 16; ++c) {
+            if (c + 1 < GG_K / 16) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    fa[(c + 1) & 1][q] = ap0[(16 * (c + 1) + 2 * q) * GG_LD];
+                    fb[(c + 1) & 1][q] = bp0[(16 * (c + 1) + 2 * q) * GG_LD];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][q], fb[c & 1][q], acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int i = i0 + 32 * wi + 8 * (v >> 2) + 4 * (ln >> 5) + (v & 3), j = j0 + 32 * wj + (ln & 31);
+        if (i >= M || j >= N) continue;
+        float val = acc[v];
+        if (P.bias) val += P.bias[j];
+        if (P.epi == 1) val *= dsilu_f(P.e0[(long)i * P.e_ld + j]);
+        else if (P.epi == 2) val *= P.alpha;
+        if (P.addend) val += P.addend[(long)i * P.add_ld + j];
+        float* dst = P.c + c_boff + (long)i * P.ldc + j;
+        if (P.accumulate == 2) atomicAdd(dst, val);          // split reductions (nbatch members sharing one C)
+        else *dst = P.accumulate ? *dst + val : val;
+    }
+#else
     float acc[4][4] = {};
     const int ty = t >> 4, tx = t & 15;
     fetch();
@@ -265,6 +317,7 @@ __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__
             else *dst = P.accumulate ? *dst + v : v;
         }
     }
+#endif
     if (want_cs) {
         cs[t >> 6][t & 63] = csum;
         __syncthreads();

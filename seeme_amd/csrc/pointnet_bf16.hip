@@ -485,11 +485,32 @@ __global__ __launch_bounds__(512) void k_pn_rows(const PnRowsArgs a) {
     if (sub == 0) a.y[which][(size_t)b * a.ldy + f] = v + (a.bias[which] != nullptr ? a.bias[which][f] : 0.f);
 }
 
+#ifndef PN_CHUNK_MB_DEFAULT
+#define PN_CHUNK_MB_DEFAULT 0
+#endif
 extern "C" int seeme_pointnet_encode_bf16(const SeemePointnetWeights* w, const SeemePointnetBf16* wb, const float* points,
                                           int B, int P, float* out, void* workspace, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (B <= 0 || P <= 0 || B > 65535) return seeme_fail("pointnet_bf16: bad sizes");
     if (ws_bytes < seeme_pointnet_bf16_workspace_bytes(B, P)) return seeme_fail("pointnet_bf16: workspace too small");
+    {   // Scene chunks: the activations between two blocks (2 x P x 512 B per scene) live in the SAME workspace region for every
+        // chunk, sized to stay in the 256 MB Infinity Cache -- a whole batch of 64 x 20 000 points writes 655 MB per block and
+        // reads it back from HBM.  SEEME_PN_CHUNK_MB: bytes of both activation buffers per chunk (0 = no chunking).
+        static long chunk_mb = -1;
+        if (chunk_mb < 0) { const char* e = getenv("SEEME_PN_CHUNK_MB"); chunk_mb = e ? atol(e) : PN_CHUNK_MB_DEFAULT; }
+        const size_t per_scene = (size_t)((P + 15) / 16 * 16) * PN_H * 2 * 2;
+        int chunk = chunk_mb > 0 ? (int)(((size_t)chunk_mb << 20) / per_scene) : B;
+        if (chunk < 1) chunk = 1;
+        if (chunk < B) {
+            for (int c0 = 0; c0 < B; c0 += chunk) {
+                const int nb = B - c0 < chunk ? B - c0 : chunk;
+                const int rc = seeme_pointnet_encode_bf16(w, wb, points + (size_t)c0 * P * 3, nb, P, out + (size_t)c0 * w->out_dim, workspace,
+                                                          seeme_pointnet_bf16_workspace_bytes(nb, P), stream);
+                if (rc) return rc;
+            }
+            return 0;
+        }
+    }
     const size_t M = (size_t)B * ((P + 15) / 16 * 16);
     unsigned short* xa = (unsigned short*)workspace;
     unsigned short* xb = xa + M * PN_H;
