@@ -83,6 +83,12 @@ __device__ __forceinline__ void p2_atomic_max(float* p, float v) {
     else atomicMin(reinterpret_cast<unsigned int*>(p), __float_as_uint(v));
 }
 
+#ifndef P2_X_AUX
+#define P2_X_AUX 0      // cache-policy bits of the activation loads (bit 1 = non-temporal)
+#endif
+#ifndef P2_ST_AUX
+#define P2_ST_AUX 0     // ... and of the activation stores
+#endif
 #ifdef P2_DBG_TIMES
 // debug build only (scripts/pn2_times.py): cycle stamps of every wave of one workgroup around the barrier and the MFMA
 // section of every step of its fourth tile
@@ -154,8 +160,8 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
     // fragment (point tile pt of the workgroup's tile, k-block kb) = 1 KiB at ((pt * 8 + kb) * 1024); this wave's point tiles: 2 wave + mt
     const unsigned f_lane = (unsigned)(wave * 2 * 8192 + lane * 16);
     auto x_load = [&](const __amdgpu_buffer_rsrc_t& rt, int kb, p2_u32x4 (&dst)[2]) {
-        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rt, f_lane, (unsigned)(kb * 1024), 0);
-        dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rt, f_lane, (unsigned)(kb * 1024 + 8192), 0);
+        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rt, f_lane, (unsigned)(kb * 1024), P2_X_AUX);
+        dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rt, f_lane, (unsigned)(kb * 1024 + 8192), P2_X_AUX);
     };
     auto issue_pts = [&](int tn) {
         const int sc = tn / a.tiles_x, q0 = (tn - sc * a.tiles_x) * P2_MT, rv = min(P2_MT, a.P - q0);
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
                                 const f32x4 u = acc1[2 * kl][mt], v = acc1[2 * kl + 1][mt];
 #ifndef P2_ABL_NOSTORE
                                 __builtin_amdgcn_raw_buffer_store_b128(p2_u32x4{p2_pack(u[0], u[1]), p2_pack(u[2], u[3]), p2_pack(v[0], v[1]), p2_pack(v[2], v[3])},
-                                                                       ro, f_lane, (unsigned)((4 * g + kl) * 1024 + mt * 8192), 0);
+                                                                       ro, f_lane, (unsigned)((4 * g + kl) * 1024 + mt * 8192), P2_ST_AUX);
 #endif
                             }
                     }
