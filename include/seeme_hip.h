@@ -449,8 +449,15 @@ int seeme_vt_softmax_fwd(float* scores, const int32_t* lengths, int B, int S, in
 int seeme_vt_softmax_bwd(float* dp, const float* p, long rows, int S, float scale, void* stream);
 /* exact GELU: dh == NULL: out = gelu(pre); else out = dh * gelu'(pre). */
 int seeme_vt_gelu(const float* pre, const float* dh, float* out, long n, void* stream);
-/* out[b,:] (+)= sum_s d[b,s,:]  (d [B,S,256]). */
-int seeme_vt_seq_sum(const float* d, float* out, int B, int S, int accumulate, void* stream);
+/* out[b,:] (+)= sum_s w[b,s] d[b,s,:]  (d [B,S,256]); w = wmask[b,s] ? scale : 0, or 1 when wmask is NULL. */
+int seeme_vt_seq_sum(const float* d, float* out, int B, int S, int accumulate, const unsigned char* wmask, float scale, void* stream);
+/* Inverted dropout with a given keep-mask (nn.Dropout / the attention-weight dropout of nn.MultiheadAttention in training,
+ * cross_attention.py:264-273,324-337): out = x * mask * scale, scale = 1 / (1 - p); in place allowed; x / out 16-byte aligned, mask 4-byte aligned. */
+int seeme_vt_dropout(const float* x, const unsigned char* mask, float scale, float* out, long n, void* stream);
+/* Decoder cross-attention to the single latent token under dropout (cross_attention.py:357-362):
+ * out[b,s,:] = ((wmask[b,s] ? scale : 0) * cvn[b,:] + bo) * (m2[b,s,:] ? scale : 0). */
+int seeme_vt_cross_rows(const float* cvn, const float* bo, const unsigned char* wmask, const unsigned char* m2, float scale,
+                        int B, int S, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -143,7 +143,9 @@ _SIGNATURES = {
     "seeme_vt_softmax_fwd": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, fp]),
     "seeme_vt_softmax_bwd": (C.c_int, [fp, fp, C.c_long, C.c_int, C.c_float, fp]),
     "seeme_vt_gelu": (C.c_int, [fp, fp, fp, C.c_long, fp]),
-    "seeme_vt_seq_sum": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, fp]),
+    "seeme_vt_seq_sum": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, fp, C.c_float, fp]),
+    "seeme_vt_dropout": (C.c_int, [fp, fp, C.c_float, fp, C.c_long, fp]),
+    "seeme_vt_cross_rows": (C.c_int, [fp, fp, fp, fp, C.c_float, C.c_int, C.c_int, fp, fp]),
     "seeme_den_vecgrad": (C.c_int, [fp, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, fp, fp]),
     "seeme_glue_rows": (C.c_int, [C.POINTER(GlueRows), fp]),
     "seeme_glue_ln": (C.c_int, [fp, fp, fp, C.c_int, fp]),

@@ -129,13 +129,41 @@ __global__ void k_vt_gelu_bwd(const float* __restrict__ dh, const float* __restr
     dpre[i] = dh[i] * (cdf + x * pdf);
 }
 
-// out[b][c] (+)= sum_s d[b][s][c]   (gradient of a per-sequence vector that was broadcast over the rows)
-__global__ __launch_bounds__(256) void k_vt_seq_sum(const float* __restrict__ d, float* __restrict__ out, int S, int accumulate) {
+// out[b][c] (+)= sum_s w[b][s] d[b][s][c]   (gradient of a per-sequence vector that was broadcast over the rows; w = the
+// dropped-out single-key attention weight mask[b][s] * scale, or 1 without dropout)
+__global__ __launch_bounds__(256) void k_vt_seq_sum(const float* __restrict__ d, float* __restrict__ out, int S, int accumulate,
+                                                    const unsigned char* __restrict__ wmask, float scale) {
     const int b = blockIdx.x, c = threadIdx.x;
     const float* p = d + (size_t)b * S * 256 + c;
     float s = 0.f;
-    for (int i = 0; i < S; ++i) s += p[(size_t)i * 256];
+    for (int i = 0; i < S; ++i) s += (wmask ? (wmask[(size_t)b * S + i] ? scale : 0.f) : 1.f) * p[(size_t)i * 256];
     out[(size_t)b * 256 + c] = accumulate ? out[(size_t)b * 256 + c] + s : s;
+}
+
+// inverted dropout with a given keep-mask: out = x * mask * scale (in place allowed); x / out 16-byte, mask 4-byte aligned
+__global__ void k_vt_dropout(const float* __restrict__ x, const unsigned char* __restrict__ m, float scale, float* __restrict__ out, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        const uchar4 k = *reinterpret_cast<const uchar4*>(m + i);
+        *reinterpret_cast<float4*>(out + i) = make_float4(k.x ? v.x * scale : 0.f, k.y ? v.y * scale : 0.f, k.z ? v.z * scale : 0.f, k.w ? v.w * scale : 0.f);
+    } else {
+        for (long j = i; j < n; ++j) out[j] = m[j] ? x[j] * scale : 0.f;
+    }
+}
+
+// The decoder's cross-attention to the single latent token WITH dropout (cross_attention.py:357-362): the softmax over one key
+// is 1, attention dropout turns it into w[b,s] in {0, scale}, dropout2 masks the projected output:
+//   out[b,s,:] = (w[b,s] * cvn[b,:] + bo) * m2[b,s,:] * scale,   cvn = out_proj.weight (W_v z + b_v)
+__global__ __launch_bounds__(256) void k_vt_cross_rows(const float* __restrict__ cvn, const float* __restrict__ bo,
+                                                       const unsigned char* __restrict__ wmask, const unsigned char* __restrict__ m2,
+                                                       float scale, int S, float* __restrict__ out) {
+    const size_t row = blockIdx.x;
+    const int c = threadIdx.x;
+    const size_t b = row / S;
+    const float w = wmask[row] ? scale : 0.f;
+    out[row * 256 + c] = m2[row * 256 + c] ? (w * cvn[b * 256 + c] + bo[c]) * scale : 0.f;
 }
 
 // ------------------------------------------------------------------ C-ABI
@@ -165,8 +193,20 @@ extern "C" int seeme_vt_gelu(const float* pre, const float* dh, float* out, long
     else hipLaunchKernelGGL(k_vt_gelu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, pre, out, n);
     return seeme_check_launch("k_vt_gelu");
 }
-extern "C" int seeme_vt_seq_sum(const float* d, float* out, int B, int S, int accumulate, void* stream) {
+extern "C" int seeme_vt_seq_sum(const float* d, float* out, int B, int S, int accumulate, const unsigned char* wmask, float scale, void* stream) {
     if (!d || !out || B < 1 || S < 1) return seeme_fail("seeme_vt_seq_sum: bad arguments");
-    hipLaunchKernelGGL(k_vt_seq_sum, dim3(B), dim3(256), 0, (hipStream_t)stream, d, out, S, accumulate);
+    hipLaunchKernelGGL(k_vt_seq_sum, dim3(B), dim3(256), 0, (hipStream_t)stream, d, out, S, accumulate, wmask, scale);
     return seeme_check_launch("k_vt_seq_sum");
+}
+extern "C" int seeme_vt_dropout(const float* x, const unsigned char* mask, float scale, float* out, long n, void* stream) {
+    if (!x || !mask || !out || n < 1 || (reinterpret_cast<size_t>(mask) & 3) || (reinterpret_cast<size_t>(x) & 15) || (reinterpret_cast<size_t>(out) & 15))
+        return seeme_fail("seeme_vt_dropout: n >= 1, x / out 16-byte aligned, mask 4-byte aligned");
+    hipLaunchKernelGGL(k_vt_dropout, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask, scale, out, n);
+    return seeme_check_launch("k_vt_dropout");
+}
+extern "C" int seeme_vt_cross_rows(const float* cvn, const float* bo, const unsigned char* wmask, const unsigned char* m2, float scale,
+                                   int B, int S, float* out, void* stream) {
+    if (!cvn || !bo || !wmask || !m2 || !out || B < 1 || S < 1) return seeme_fail("seeme_vt_cross_rows: bad arguments");
+    hipLaunchKernelGGL(k_vt_cross_rows, dim3((unsigned)((size_t)B * S)), dim3(256), 0, (hipStream_t)stream, cvn, bo, wmask, m2, scale, S, out);
+    return seeme_check_launch("k_vt_cross_rows");
 }

@@ -1,10 +1,11 @@
 """Differentiable twins for STAGE-1 training (``TRAIN.STAGE: vae``): the motion VAE and the SMPL joint regressor in
 plain PyTorch ops on the same parameters / buffers as the HIP modules, so that ``MLD.train_vae_forward`` has a backward
-(PyTorch-ROCm autograd on the device).  Inference and stage-2 never route through here; a hand-written backward for this
-stage is not built yet.  Checked against the HIP forward in
+(PyTorch-ROCm autograd on the device).  Since round 2 the training path is the hand-written HIP forward / backward of
+``vae_train.py`` and ``smpl._JointsAA``; these twins are its fallback (shapes the kernels do not take,
+``TRAIN.HIP_VAE_BACKWARD: false``) and its test oracle.  Checked against the HIP forward in
 tests/test_gpu_parity.py::test_vae_autograd_twin_matches_hip.
 
-Reference: mld_vae.py:128-256, cross_attention.py:41-147,281-367 (eval-mode arithmetic: dropout off, as the HIP path);
+Reference: mld_vae.py:128-256, cross_attention.py:41-147,281-367 (dropout at the reference's sites in training mode);
 smplx lbs: shape blend -> joint regression -> Rodrigues -> pose blend is irrelevant for joints ->
 kinematic chain -> posed joints + translation.
 """
@@ -17,7 +18,26 @@ import torch
 import torch.nn.functional as F
 
 
-def _mha(lp, q_in, k_in, v_in, nhead: int, key_padding_mask=None):
+class Dropper:
+    """The dropout of the reference's layers (cross_attention.py:264-273,324-337).  ``masks``: injected keep-masks by site name
+    (tests: the very masks the HIP path drew); otherwise F.dropout with probability p when ``training``; identity in eval."""
+
+    def __init__(self, p: float = 0.0, training: bool = False, masks=None):
+        self.p, self.training, self.masks = float(p), bool(training), masks
+
+    def __call__(self, x, site: str):
+        if self.masks is not None:
+            m = self.masks[site].reshape(x.shape).to(x.dtype)
+            return x * m * (1.0 / (1.0 - self.p))
+        if self.training and self.p > 0:
+            return F.dropout(x, self.p, True)
+        return x
+
+
+_NO_DROP = Dropper()
+
+
+def _mha(lp, q_in, k_in, v_in, nhead: int, key_padding_mask=None, drop=_NO_DROP, site=""):
     """nn.MultiheadAttention arithmetic, batch-first [B,S,D]; key_padding_mask bool [B,Sk], True = ignore."""
     w, b = lp.in_proj_weight, lp.in_proj_bias
     D = q_in.shape[-1]
@@ -32,7 +52,7 @@ def _mha(lp, q_in, k_in, v_in, nhead: int, key_padding_mask=None):
     s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
     if key_padding_mask is not None:
         s = s.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
-    o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, Sq, D)
+    o = (drop(torch.softmax(s, dim=-1), site) @ v).transpose(1, 2).reshape(B, Sq, D)
     return F.linear(o, lp.out_proj.weight, lp.out_proj.bias)
 
 
@@ -40,28 +60,35 @@ def _ln(x, n):
     return F.layer_norm(x, (x.shape[-1],), n.weight, n.bias)
 
 
-def _enc_layer(lp, x, nhead, kpm):                                   # forward_post, cross_attention.py:281-294
-    x = _ln(x + _mha(lp.self_attn, x, x, x, nhead, kpm), lp.norm1)
-    return _ln(x + F.linear(F.gelu(F.linear(x, lp.linear1.weight, lp.linear1.bias)), lp.linear2.weight, lp.linear2.bias), lp.norm2)
+def _enc_layer(lp, x, nhead, kpm, drop=_NO_DROP, l=0):               # forward_post, cross_attention.py:281-294
+    x = _ln(x + drop(_mha(lp.self_attn, x, x, x, nhead, kpm, drop, f"{l}.mP"), f"{l}.m1"), lp.norm1)
+    h = drop(F.gelu(F.linear(x, lp.linear1.weight, lp.linear1.bias)), f"{l}.mh")
+    return _ln(x + drop(F.linear(h, lp.linear2.weight, lp.linear2.bias), f"{l}.m2"), lp.norm2)
 
 
-def _dec_layer(lp, x, mem, nhead, kpm):                              # forward_post, cross_attention.py:345-367
-    x = _ln(x + _mha(lp.self_attn, x, x, x, nhead, kpm), lp.norm1)
-    x = _ln(x + _mha(lp.multihead_attn, x, mem, mem, nhead, None), lp.norm2)
-    return _ln(x + F.linear(F.gelu(F.linear(x, lp.linear1.weight, lp.linear1.bias)), lp.linear2.weight, lp.linear2.bias), lp.norm3)
+def _dec_layer(lp, x, mem, nhead, kpm, drop=_NO_DROP, l=0):          # forward_post, cross_attention.py:345-367
+    x = _ln(x + drop(_mha(lp.self_attn, x, x, x, nhead, kpm, drop, f"{l}.mP"), f"{l}.m1"), lp.norm1)
+    x = _ln(x + drop(_mha(lp.multihead_attn, x, mem, mem, nhead, None, drop, f"{l}.mw"), f"{l}.mc"), lp.norm2)
+    h = drop(F.gelu(F.linear(x, lp.linear1.weight, lp.linear1.bias)), f"{l}.mh")
+    return _ln(x + drop(F.linear(h, lp.linear2.weight, lp.linear2.bias), f"{l}.m2"), lp.norm3)
 
 
-def _skip_stack(stack, x, layer_fn):                                  # cross_attention.py:46-65,118-147
+def _skip_stack(stack, x, layer_fn):                                  # cross_attention.py:46-65,118-147; layer_fn(lp, x, index)
     nb = len(stack.input_blocks)
     xs = []
     for i in range(nb):
-        x = layer_fn(stack.input_blocks[i], x)
+        x = layer_fn(stack.input_blocks[i], x, i)
         xs.append(x)
-    x = layer_fn(stack.middle_block, x)
+    x = layer_fn(stack.middle_block, x, nb)
     for i in range(nb):
         x = F.linear(torch.cat([x, xs.pop()], dim=-1), stack.linear_blocks[i].weight, stack.linear_blocks[i].bias)
-        x = layer_fn(stack.output_blocks[i], x)
+        x = layer_fn(stack.output_blocks[i], x, nb + 1 + i)
     return _ln(x, stack.norm)
+
+
+def _dropper(vae, masks):
+    p = float(vae.encoder.input_blocks[0].self_attn.dropout)
+    return Dropper(p, vae.training, masks)
 
 
 def _mask(lengths: List[int], device):
@@ -69,8 +96,9 @@ def _mask(lengths: List[int], device):
     return torch.arange(int(max(lengths)), device=device)[None, :] < lens[:, None]
 
 
-def vae_encode_torch(vae, features: torch.Tensor, lengths: List[int]):
-    """features [B,T,F] -> (mu [1,B,256], std [1,B,256]) (mld_vae.py:128-193)."""
+def vae_encode_torch(vae, features: torch.Tensor, lengths: List[int], masks=None):
+    """features [B,T,F] -> (mu [1,B,256], std [1,B,256]) (mld_vae.py:128-193).  Dropout as the module's mode says; `masks`:
+    injected keep-masks {"<layer>.<site>": tensor} (tests)."""
     B = features.shape[0]
     nhead = vae.encoder.input_blocks[0].self_attn.num_heads
     mask = _mask(lengths, features.device)
@@ -79,19 +107,21 @@ def vae_encode_torch(vae, features: torch.Tensor, lengths: List[int]):
     aug = torch.cat([torch.ones(B, tok.shape[1], dtype=torch.bool, device=x.device), mask], dim=1)
     xseq = torch.cat([tok, x], dim=1)
     xseq = xseq + vae.query_pos_encoder.pe[: xseq.shape[1], 0][None]
-    out = _skip_stack(vae.encoder, xseq, lambda lp, h: _enc_layer(lp, h, nhead, ~aug))
+    drop = _dropper(vae, masks)
+    out = _skip_stack(vae.encoder, xseq, lambda lp, h, l: _enc_layer(lp, h, nhead, ~aug, drop, l))
     mu, logvar = out[:, 0], out[:, 1]
     return mu[None], logvar.exp().pow(0.5)[None]
 
 
-def vae_decode_torch(vae, z: torch.Tensor, lengths: List[int]):
+def vae_decode_torch(vae, z: torch.Tensor, lengths: List[int], masks=None):
     """z [1,B,256] -> feats [B,T,F] (mld_vae.py:195-256, arch encoder_decoder; padded frames not zeroed, :253)."""
     nhead = vae.decoder.input_blocks[0].self_attn.num_heads
     mask = _mask(lengths, z.device)
     B, T = mask.shape
     q = vae.query_pos_decoder.pe[:T, 0][None].expand(B, -1, -1)
     mem = z.permute(1, 0, 2)
-    out = _skip_stack(vae.decoder, q, lambda lp, h: _dec_layer(lp, h, mem, nhead, ~mask))
+    drop = _dropper(vae, masks)
+    out = _skip_stack(vae.decoder, q, lambda lp, h, l: _dec_layer(lp, h, mem, nhead, ~mask, drop, l))
     return F.linear(out, vae.final_layer.weight, vae.final_layer.bias)
 
 

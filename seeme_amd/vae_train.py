@@ -14,9 +14,10 @@ them.  Inside a node everything is launches of ``libseeme_hip.so``:
   vector of the single latent token is one row per sequence).
 
 Parameter gradients are accumulated straight into ``.grad`` (the views of ``distributed.GradBucket`` once it exists).
-Arithmetic is the eval-mode arithmetic of the HIP inference path and of the autograd twin (``vae_autograd.py``: no
-dropout), which stays as the fallback (more than one head, S > 512) and as the oracle of
-``tests/test_gpu_flows.py::test_vae_hip_backward_matches_autograd``.
+In training mode the reference's dropout sites are applied (attention weights of ``nn.MultiheadAttention``, ``dropout1/2/3``, the
+FFN's inner dropout; cross_attention.py:264-273,324-337) with keep-masks drawn by one ``bernoulli_`` per stack and step; in eval
+mode the arithmetic is that of the HIP inference path.  The autograd twin (``vae_autograd.py``) stays as the fallback (more than
+one head, S > 512) and as the oracle of ``tests/test_gpu_flows.py::test_vae_hip_backward_matches_autograd`` (with the same masks).
 """
 from __future__ import annotations
 
@@ -75,6 +76,9 @@ class _Ops:
         a.dgamma, a.dbeta, a.M, a.accumulate = P(norm.weight.grad), P(norm.bias.grad), M, 0
         self.ops.append(lambda a=a: L.check(L.lib().seeme_vt_ln_bwd(C.byref(a), L.current_stream()), "seeme_vt_ln_bwd"))
 
+    def dropout(self, x, mask, scale, out, n):
+        self.ops.append(lambda: L.check(L.lib().seeme_vt_dropout(x, mask, scale, out, n, L.current_stream()), "seeme_vt_dropout"))
+
     def call(self, fn):
         self.ops.append(fn)
 
@@ -86,8 +90,9 @@ class _Ops:
 class _StackPlan:
     """Buffers and recorded launches of one skip stack (encoder or decoder) for a batch shape."""
 
-    def __init__(self, vae, dec: bool, B: int, T: int):
+    def __init__(self, vae, dec: bool, B: int, T: int, drop: float = 0.0):
         self.vae, self.dec, self.B, self.T = vae, dec, B, T
+        self.drop, self.dscale = float(drop), 1.0 / (1.0 - float(drop))
         self.S = S = T if dec else T + 2
         self.M = M = B * S
         self.F = vae.nfeats
@@ -107,6 +112,18 @@ class _StackPlan:
             if dec:
                 d.update(vc=z(B, 256), cv=z(B, 256), x1b=z(M, 256), xh1b=z(M, 256), rs1b=z(M))
             self.sv.append(d)
+        if self.drop > 0:      # keep-masks of every dropout site of the stack, drawn by ONE bernoulli_ per forward
+            r16 = lambda n: (n + 15) // 16 * 16
+            sizes = [("mP", B * S * S), ("m1", M * 256), ("mh", M * 128), ("m2", M * 256)] + ([("mw", B * S), ("mc", M * 256)] if dec else [])
+            per = sum(r16(n) for _, n in sizes)
+            self.masks = torch.zeros(5 * per, dtype=torch.uint8, device=dev)
+            for l, d in enumerate(self.sv):
+                o = l * per
+                for name, n in sizes:
+                    d[name] = self.masks[o:o + n]
+                    o += r16(n)
+                d["Pd"] = z(B, S, S)
+            self.Gm = z(M, 256)
         self.xs = [z(M, 256), z(M, 256)]          # outputs of the two skip linears
         self.yn, self.xhn, self.rsn = z(M, 256), z(M, 256), z(M)
         self.tmp = z(M, 256)                      # forward temporary (attention / FFN output before the LayerNorm)
@@ -145,9 +162,16 @@ class _StackPlan:
         n_prefix = 0 if self.dec else 2
         ops.call(lambda p=P(sv["P"]): L.check(L.lib().seeme_vt_softmax_fwd(p, P(self.lengths), B, S, n_prefix, 1.0 / 16.0, L.current_stream()),
                                               "seeme_vt_softmax_fwd"))
-        ops.gemm(_prob([P(sv["P"])], [q + 4 * 512], [S], [1], [768], S, 1, P(sv["O"]), 256, S, 256, nbatch=B,
+        dr, ds = self.drop > 0, self.dscale
+        pv = P(sv["P"])
+        if dr:                                                   # attention-weight dropout of nn.MultiheadAttention
+            ops.dropout(P(sv["P"]), P(sv["mP"]), ds, P(sv["Pd"]), B * S * S)
+            pv = P(sv["Pd"])
+        ops.gemm(_prob([pv], [q + 4 * 512], [S], [1], [768], S, 1, P(sv["O"]), 256, S, 256, nbatch=B,
                        bstrides=(S * S, S * 768, S * 256)))
         ops.gemm(_gemm_fwd([P(sv["O"])], 256, P(sa.out_proj.weight), 256, [256], P(sa.out_proj.bias), P(self.tmp), 256, M, 256))
+        if dr:
+            ops.dropout(P(self.tmp), P(sv["m1"]), ds, P(self.tmp), M * 256)           # dropout1
         ops.add_ln(P(self.tmp), x_in, lp.norm1, P(sv["x1"]), P(sv["xh1"]), P(sv["rs1"]), M)
         x1 = P(sv["x1"])
         n_ffn = lp.norm2
@@ -155,19 +179,31 @@ class _StackPlan:
             ca = lp.multihead_attn
             ops.gemm(_gemm_fwd([P(self.zb)], 256, P(ca.in_proj_weight) + 4 * 512 * 256, 256, [256], P(ca.in_proj_bias) + 4 * 512,
                                P(sv["vc"]), 256, B, 256))
-            ops.gemm(_gemm_fwd([P(sv["vc"])], 256, P(ca.out_proj.weight), 256, [256], P(ca.out_proj.bias), P(sv["cv"]), 256, B, 256))
-            ops.add_ln(P(sv["cv"]), x1, lp.norm2, P(sv["x1b"]), P(sv["xh1b"]), P(sv["rs1b"]), M, sub_seq_rows=S)
+            if dr:       # cv = W_o v without the bias; per row (w[b,s] cv[b] + b_o) * dropout2 mask
+                ops.gemm(_gemm_fwd([P(sv["vc"])], 256, P(ca.out_proj.weight), 256, [256], 0, P(sv["cv"]), 256, B, 256))
+                ops.call(lambda: L.check(L.lib().seeme_vt_cross_rows(P(sv["cv"]), P(ca.out_proj.bias), P(sv["mw"]), P(sv["mc"]), ds, B, S,
+                                                                      P(self.tmp), L.current_stream()), "seeme_vt_cross_rows"))
+                ops.add_ln(P(self.tmp), x1, lp.norm2, P(sv["x1b"]), P(sv["xh1b"]), P(sv["rs1b"]), M)
+            else:
+                ops.gemm(_gemm_fwd([P(sv["vc"])], 256, P(ca.out_proj.weight), 256, [256], P(ca.out_proj.bias), P(sv["cv"]), 256, B, 256))
+                ops.add_ln(P(sv["cv"]), x1, lp.norm2, P(sv["x1b"]), P(sv["xh1b"]), P(sv["rs1b"]), M, sub_seq_rows=S)
             x1 = P(sv["x1b"])
             n_ffn = lp.norm3
         ops.gemm(_gemm_fwd([x1], 256, P(lp.linear1.weight), 256, [256], P(lp.linear1.bias), P(sv["hpre"]), 128, M, 128))
         ops.call(lambda a=P(sv["hpre"]), o=P(sv["h"]): L.check(L.lib().seeme_vt_gelu(a, 0, o, M * 128, L.current_stream()), "seeme_vt_gelu"))
+        if dr:
+            ops.dropout(P(sv["h"]), P(sv["mh"]), ds, P(sv["h"]), M * 128)               # dropout inside the FFN
         ops.gemm(_gemm_fwd([P(sv["h"])], 128, P(lp.linear2.weight), 128, [128], P(lp.linear2.bias), P(self.tmp), 256, M, 256))
+        if dr:
+            ops.dropout(P(self.tmp), P(sv["m2"]), ds, P(self.tmp), M * 256)           # dropout2 (decoder: dropout3)
         ops.add_ln(P(self.tmp), x1, n_ffn, P(sv["x2"]), P(sv["xh2"]), P(sv["rs2"]), M)
         return P(sv["x2"])
 
     def _record_forward(self) -> _Ops:
         ops = _Ops(self.dev)
         v, B, S, T, M, F = self.vae, self.B, self.S, self.T, self.M, self.F
+        if self.drop > 0:
+            ops.call(lambda: self.masks.bernoulli_(1.0 - self.drop))
         if not self.dec:
             emb = v.skel_embedding
             ops.gemm(_prob([P(self.feat_in)], [P(emb.weight)], [F], [1], [1], F, F, P(self.x0) + 4 * 2 * 256, 256, T, 256, bias=P(emb.bias),
@@ -203,35 +239,58 @@ class _StackPlan:
         G = lambda t: t.grad.data_ptr()
         n_ffn = lp.norm3 if self.dec else lp.norm2
         x1 = P(sv["x1b"]) if self.dec else P(sv["x1"])
+        dr, ds = self.drop > 0, self.dscale
         ops.ln_bwd(dy, dy2, P(sv["xh2"]), P(sv["rs2"]), n_ffn, P(self.G2), M)
-        ops.gemm(_gemm_dgrad(P(self.G2), 256, P(lp.linear2.weight), 128, 256, 128, P(self.dh), 128, M))
+        g2 = P(self.G2)                                          # gradient of the FFN output: behind its dropout mask
+        if dr:
+            ops.dropout(P(self.G2), P(sv["m2"]), ds, P(self.Gm), M * 256)
+            g2 = P(self.Gm)
+        ops.gemm(_gemm_dgrad(g2, 256, P(lp.linear2.weight), 128, 256, 128, P(self.dh), 128, M),
+                 _gemm_wgrad(g2, 256, P(sv["h"]), 128, S, B, G(lp.linear2.weight), 128, 256, 128, G(lp.linear2.bias)))
+        if dr:
+            ops.dropout(P(self.dh), P(sv["mh"]), ds, P(self.dh), M * 128)
         ops.call(lambda: L.check(L.lib().seeme_vt_gelu(P(sv["hpre"]), P(self.dh), P(self.dhpre), M * 128, L.current_stream()), "seeme_vt_gelu"))
         ops.gemm(_gemm_dgrad(P(self.dhpre), 128, P(lp.linear1.weight), 256, 128, 256, P(self.DX1), 256, M, addend=P(self.G2), add_ld=256))
-        wg = [_gemm_wgrad(P(self.G2), 256, P(sv["h"]), 128, S, B, G(lp.linear2.weight), 128, 256, 128, G(lp.linear2.bias)),
-              _gemm_wgrad(P(self.dhpre), 128, x1, 256, S, B, G(lp.linear1.weight), 256, 128, 256, G(lp.linear1.bias))]
+        wg = [_gemm_wgrad(P(self.dhpre), 128, x1, 256, S, B, G(lp.linear1.weight), 256, 128, 256, G(lp.linear1.bias))]
         d_x1 = P(self.DX1)
         if self.dec:
             ca = lp.multihead_attn
             ops.ln_bwd(P(self.DX1), 0, P(sv["xh1b"]), P(sv["rs1b"]), lp.norm2, P(self.G1b), M)
-            ops.call(lambda: L.check(L.lib().seeme_vt_seq_sum(P(self.G1b), P(self.dcv), B, S, 0, L.current_stream()), "seeme_vt_seq_sum"))
+            if dr:
+                ops.dropout(P(self.G1b), P(sv["mc"]), ds, P(self.Gm), M * 256)
+
+                def bias_grad(ca=ca):
+                    ca.out_proj.bias.grad += self.Gm.sum(0)
+                ops.call(bias_grad)
+                ops.call(lambda: L.check(L.lib().seeme_vt_seq_sum(P(self.Gm), P(self.dcv), B, S, 0, P(sv["mw"]), ds, L.current_stream()),
+                                         "seeme_vt_seq_sum"))
+            else:
+                ops.call(lambda: L.check(L.lib().seeme_vt_seq_sum(P(self.G1b), P(self.dcv), B, S, 0, 0, 1.0, L.current_stream()), "seeme_vt_seq_sum"))
             ops.gemm(_gemm_dgrad(P(self.dcv), 256, P(ca.out_proj.weight), 256, 256, 256, P(self.dvc), 256, B))
             ops.gemm(_gemm_dgrad(P(self.dvc), 256, P(ca.in_proj_weight) + 4 * 512 * 256, 256, 256, 256, P(self.dz), 256, B, accumulate=1),
-                     _gemm_wgrad(P(self.dcv), 256, P(sv["vc"]), 256, B, 1, G(ca.out_proj.weight), 256, 256, 256, G(ca.out_proj.bias)),
+                     _gemm_wgrad(P(self.dcv), 256, P(sv["vc"]), 256, B, 1, G(ca.out_proj.weight), 256, 256, 256, 0 if dr else G(ca.out_proj.bias)),
                      _gemm_wgrad(P(self.dvc), 256, P(self.zb), 256, B, 1, G(ca.in_proj_weight) + 4 * 512 * 256, 256, 256, 256,
                                  G(ca.in_proj_bias) + 4 * 512))
             d_x1 = P(self.G1b)
         ops.ln_bwd(d_x1, 0, P(sv["xh1"]), P(sv["rs1"]), lp.norm1, P(self.G1), M)
-        ops.gemm(_gemm_dgrad(P(self.G1), 256, P(sa.out_proj.weight), 256, 256, 256, P(self.dO), 256, M))
+        g1 = P(self.G1)                                          # gradient of the attention output: behind dropout1
+        if dr:
+            ops.dropout(P(self.G1), P(sv["m1"]), ds, P(self.Gm), M * 256)
+            g1 = P(self.Gm)
+        ops.gemm(_gemm_dgrad(g1, 256, P(sa.out_proj.weight), 256, 256, 256, P(self.dO), 256, M),
+                 _gemm_wgrad(g1, 256, P(sv["O"]), 256, S, B, G(sa.out_proj.weight), 256, 256, 256, G(sa.out_proj.bias)))
         q, dq = P(sv["qkv"]), P(self.dqkv)
+        pv = P(sv["Pd"]) if dr else P(sv["P"])
         ops.gemm(_prob([P(self.dO)], [q + 4 * 512], [256], [1], [1], 256, 768, P(self.dP), S, S, S, nbatch=B, bstrides=(S * 256, S * 768, S * S)),
-                 _prob([P(sv["P"])], [P(self.dO)], [S], [S], [256], 1, 1, dq + 4 * 512, 768, S, 256, nbatch=B, bstrides=(S * S, S * 256, S * 768)))
+                 _prob([pv], [P(self.dO)], [S], [S], [256], 1, 1, dq + 4 * 512, 768, S, 256, nbatch=B, bstrides=(S * S, S * 256, S * 768)))
+        if dr:
+            ops.dropout(P(self.dP), P(sv["mP"]), ds, P(self.dP), B * S * S)
         ops.call(lambda: L.check(L.lib().seeme_vt_softmax_bwd(P(self.dP), P(sv["P"]), B * S, S, 1.0 / 16.0, L.current_stream()),
                                  "seeme_vt_softmax_bwd"))
         ops.gemm(_prob([P(self.dP)], [q + 4 * 256], [S], [1], [768], S, 1, dq, 768, S, 256, nbatch=B, bstrides=(S * S, S * 768, S * 768)),
                  _prob([P(self.dP)], [q], [S], [S], [768], 1, 1, dq + 4 * 256, 768, S, 256, nbatch=B, bstrides=(S * S, S * 768, S * 768)))
         ops.gemm(_gemm_dgrad(dq, 768, P(sa.in_proj_weight), 256, 768, 256, out, 256, M, addend=P(self.G1), add_ld=256))
-        wg += [_gemm_wgrad(P(self.G1), 256, P(sv["O"]), 256, S, B, G(sa.out_proj.weight), 256, 256, 256, G(sa.out_proj.bias)),
-               _gemm_wgrad(dq, 768, x_in, 256, S, B, G(sa.in_proj_weight), 256, 768, 256, G(sa.in_proj_bias))]
+        wg += [_gemm_wgrad(dq, 768, x_in, 256, S, B, G(sa.in_proj_weight), 256, 768, 256, G(sa.in_proj_bias))]
         ops.gemm(*wg)
 
     def record_backward(self):
@@ -349,10 +408,13 @@ class VaeTrainer:
         return tuple(p.data_ptr() for p in self.vae.parameters()) != self._key
 
     def plan(self, dec: bool, B: int, T: int) -> _StackPlan:
-        k = (dec, B, T)
+        # training mode: the reference's dropout sites (nn.MultiheadAttention weights, dropout1/2/3, the FFN's inner dropout;
+        # cross_attention.py:264-273,324-337) with p of the module; eval mode: none
+        drop = float(self.vae.encoder.input_blocks[0].self_attn.dropout) if self.vae.training else 0.0
+        k = (dec, B, T, drop)
         p = self.plans.get(k)
         if p is None or p.busy:           # busy: a second forward before the first one's backward keeps that one's saved tensors
-            p = _StackPlan(self.vae, dec, B, T)
+            p = _StackPlan(self.vae, dec, B, T, drop)
             self.plans[k] = p
         return p
 

@@ -464,3 +464,54 @@ def test_vae_hip_backward_matches_autograd(dev, cfg_name, B, T):
         scale = max(float(v.abs().max()) for v in g0.values())
         errs = sorted(((float((g1[k] - g0[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-4 * scale), k) for k in g0), reverse=True)
         assert errs[0][0] < 1e-4, (it, errs[:6])
+
+
+def test_vae_hip_training_dropout_matches_twin_with_same_masks(dev):
+    """Training mode: vae_train.py applies the reference's dropout sites (attention weights, dropout1/2/3, the FFN's inner
+    dropout, the dropped-out single-key cross-attention weight; cross_attention.py:264-273,324-337) with keep-masks it draws
+    itself.  With those very masks injected into the autograd twin, outputs and every parameter gradient agree; the masks keep
+    ~90 % of the elements; eval mode draws none."""
+    from seeme_amd.vae_train import VaeTrainer
+    from seeme_amd.vae_autograd import vae_encode_torch, vae_decode_torch
+    from test_gpu_parity import make_vae
+    B, T = 3, 21
+    lengths = [21, 13, 17]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, T, 75, generator=g).to(dev)
+    eps, w1 = torch.randn(1, B, 256, generator=g).to(dev), torch.randn(B, T, 75, generator=g).to(dev)
+    w2, w3 = torch.randn(1, B, 256, generator=g).to(dev), torch.randn(1, B, 256, generator=g).to(dev) * 0.1
+    vae = make_vae(75, dev).train()
+    p = float(vae.encoder.input_blocks[0].self_attn.dropout)
+    assert p == 0.1
+
+    def loss_of(mu, logvar, dec):
+        z = mu + eps * logvar.exp().pow(0.5)
+        feats = dec(z)
+        return (feats * w1).sum() + (mu * w2).sum() + (logvar * w3).sum(), feats
+
+    tr = VaeTrainer(vae)
+    torch.manual_seed(0)
+    mu, logvar = tr.encode(x, lengths)
+    loss, feats = loss_of(mu, logvar, lambda z: tr.decode(z, lengths))
+    pe, pd = tr.plans[(False, B, T, p)], tr.plans[(True, B, T, p)]
+    masks_e = {f"{l}.{k}": sv[k].clone() for l, sv in enumerate(pe.sv) for k in ("mP", "m1", "mh", "m2")}
+    masks_d = {f"{l}.{k}": sv[k].clone() for l, sv in enumerate(pd.sv) for k in ("mP", "m1", "mh", "m2", "mw", "mc")}
+    keep = float(torch.cat([m.float().flatten() for m in masks_e.values()]).mean())
+    assert abs(keep - (1 - p)) < 0.01, keep
+    loss.backward()
+    g1 = {k: v.grad.detach().clone() for k, v in vae.named_parameters() if v.grad is not None}
+    out1 = (mu.detach().clone(), logvar.detach().clone(), feats.detach().clone())
+    for q in vae.parameters():
+        q.grad = None
+    mu0, std0 = vae_encode_torch(vae, x, lengths, masks=masks_e)
+    loss0, feats0 = loss_of(mu0, 2 * std0.log(), lambda z: vae_decode_torch(vae, z, lengths, masks=masks_d))
+    loss0.backward()
+    g0 = {k: v.grad.detach().clone() for k, v in vae.named_parameters() if v.grad is not None}
+    assert rel_err(_np(out1[0]), _np(mu0)) < 2e-5 and rel_err(_np(out1[2]), _np(feats0)) < 2e-5
+    assert abs(float(loss.detach()) - float(loss0.detach())) < 2e-5 * abs(float(loss0.detach()))
+    scale = max(float(v.abs().max()) for v in g0.values())
+    errs = sorted(((float((g1[k] - g0[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-4 * scale), k) for k in g0), reverse=True)
+    assert errs[0][0] < 1e-4, errs[:6]
+    vae.eval()                                               # eval mode: a plan without masks
+    tr.encode(x, lengths)
+    assert (False, B, T, 0.0) in tr.plans and not hasattr(tr.plans[(False, B, T, 0.0)], "masks")
