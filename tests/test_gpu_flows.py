@@ -515,3 +515,32 @@ def test_vae_hip_training_dropout_matches_twin_with_same_masks(dev):
     vae.eval()                                               # eval mode: a plan without masks
     tr.encode(x, lengths)
     assert (False, B, T, 0.0) in tr.plans and not hasattr(tr.plans[(False, B, T, 0.0)], "masks")
+
+
+@pytest.mark.parametrize("argv,checks", [
+    (["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-parity-check", "--streams", "2", "--graph"],
+     {"metric": "sampled seqs/sec (T=196, 50 DDIM steps)", "n_gpus": 1}),
+    (["--steps", "2", "--warmup", "1", "--mode", "train", "--train-config", "gimo", "--points", "2048"],
+     {"n_gpus": 1}),
+    (["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity-check", "--scheduler", "ddpm", "--batch", "8"],
+     {"n_gpus": 1}),
+])
+def test_bench_modes_emit_the_contract_line(dev, argv, checks):
+    """bench.py as the driver runs it (a child process, one JSON line on stdout): the --streams / --graph sampling mode (each pass
+    replayed as a hipGraph, two batches in flight), the stage-2 training mode on the GIMO configuration, and the 1000-step DDPM
+    configuration -- every line carries the contract's fields, a roofline object and a positive value."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["steps"] == int(argv[1]) and "workload" in d["config"]
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1
+    for k, v in checks.items():
+        assert d[k] == v, (k, d[k])
