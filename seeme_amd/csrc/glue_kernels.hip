@@ -121,7 +121,7 @@ typedef float __attribute__((address_space(1))) gfloat;
 __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__ probs, int n_probs) {
     __shared__ float As[GG_K][GG_LD];
     __shared__ float Bs[GG_K][GG_LD];
-    __shared__ float cs[4][GG_T];
+    __shared__ float cs[16][GG_T];
     __shared__ int s_prob;
     const int t = threadIdx.x;
     if (t == 0) {                       // last problem whose first tile is <= blockIdx.x (tile0 is ascending)
@@ -143,13 +143,16 @@ __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__
     const int M = P.M, N = P.N, nseg = P.nseg, a_pro = P.a_pro, b_pro = P.b_pro;
     const long a_rs = P.a_rs, b_cs = P.b_cs;
     const bool a_icontig = (a_rs == 1), b_jcontig = (b_cs == 1);      // else k is taken as the contiguous one
-    // element e (0..GG_E-1) of this thread in a k-step: 16-wide k sub-block e/4, position e%4 inside the sub-block's 64 x 16
-    auto a_i = [&](int e) { return a_icontig ? (t & 63) : (t >> 4) + 16 * (e & 3); };
-    auto a_k = [&](int e) { return 16 * (e >> 2) + (a_icontig ? (t >> 6) + 4 * (e & 3) : (t & 15)); };
-    auto b_j = [&](int e) { return b_jcontig ? (t & 63) : (t >> 4) + 16 * (e & 3); };
-    auto b_k = [&](int e) { return 16 * (e >> 2) + (b_jcontig ? (t >> 6) + 4 * (e & 3) : (t & 15)); };
-    const bool want_cs = P.colsum != nullptr && j0 == 0;      // host guarantees a_rs == 1 there: one i per thread
-    float csum = 0.f;
+    // element e (0..GG_E-1) of this thread in a k-step: 16-wide k sub-block e/4; the four elements e%4 are CONSECUTIVE along
+    // the operand's contiguous dimension, so that an interior, 16-byte-aligned tile loads them as one dwordx4
+    auto a_i = [&](int e) { return a_icontig ? 4 * (t & 15) + (e & 3) : (t >> 2); };
+    auto a_k = [&](int e) { return 16 * (e >> 2) + (a_icontig ? (t >> 4) : 4 * (t & 3) + (e & 3)); };
+    auto b_j = [&](int e) { return b_jcontig ? 4 * (t & 15) + (e & 3) : (t >> 2); };
+    auto b_k = [&](int e) { return 16 * (e >> 2) + (b_jcontig ? (t >> 4) : 4 * (t & 3) + (e & 3)); };
+    const bool want_cs = P.colsum != nullptr && j0 == 0;      // host guarantees a_rs == 1 there: four i per thread
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    typedef float gg_f32x4 __attribute__((ext_vector_type(4)));
+    typedef gg_f32x4 __attribute__((address_space(1))) gfloat4;
     float ra[GG_E], rb[GG_E];
     int seg = 0, k0 = 0;
     // loads are unconditional (offset clamped to element 0 when out of range, zeroed in stage()): a load under a divergent
@@ -161,14 +164,37 @@ __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__
         const gfloat* bp = (const gfloat*)P.b[seg] + b_boff;
         const int len = P.seg_len[seg];
         const long aks = P.a_ks[seg], bks = P.b_ks[seg];
+        const bool inner_k = k0 + GG_K <= len;
+        // whole 64 x 64 operand tile in range, the contiguous stride 1 and everything a multiple of 4 floats: dwordx4 loads
+        const bool fa = inner_k && i0 + GG_T <= M && (a_icontig ? (aks & 3) == 0 : (aks == 1 && (a_rs & 3) == 0)) && (((size_t)ap) & 15) == 0;
+        const bool fb = inner_k && j0 + GG_T <= N && (b_jcontig ? (bks & 3) == 0 : (bks == 1 && (b_cs & 3) == 0)) && (((size_t)bp) & 15) == 0;
+        if (fa) {
 #pragma unroll
-        for (int e = 0; e < GG_E; ++e) {
-            const int k = k0 + a_k(e), i = i0 + a_i(e);
-            const long oa = (long)i * a_rs + (long)k * aks;
-            ra[e] = ap[(k < len && i < M) ? oa : 0];
-            const int kb = k0 + b_k(e), j = j0 + b_j(e);
-            const long ob = (long)kb * bks + (long)j * b_cs;
-            rb[e] = bp[(kb < len && j < N) ? ob : 0];
+            for (int g = 0; g < GG_E / 4; ++g) {
+                const gg_f32x4 v = *(const gfloat4*)(ap + (long)(i0 + a_i(4 * g)) * a_rs + (long)(k0 + a_k(4 * g)) * aks);
+                ra[4 * g] = v.x; ra[4 * g + 1] = v.y; ra[4 * g + 2] = v.z; ra[4 * g + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < GG_E; ++e) {
+                const int k = k0 + a_k(e), i = i0 + a_i(e);
+                const long oa = (long)i * a_rs + (long)k * aks;
+                ra[e] = ap[(k < len && i < M) ? oa : 0];
+            }
+        }
+        if (fb) {
+#pragma unroll
+            for (int g = 0; g < GG_E / 4; ++g) {
+                const gg_f32x4 v = *(const gfloat4*)(bp + (long)(k0 + b_k(4 * g)) * bks + (long)(j0 + b_j(4 * g)) * b_cs);
+                rb[4 * g] = v.x; rb[4 * g + 1] = v.y; rb[4 * g + 2] = v.z; rb[4 * g + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < GG_E; ++e) {
+                const int kb = k0 + b_k(e), j = j0 + b_j(e);
+                const long ob = (long)kb * bks + (long)j * b_cs;
+                rb[e] = bp[(kb < len && j < N) ? ob : 0];
+            }
         }
     };
     auto stage = [&](int kbase, int len) {       // prologues, zero padding, LDS (kbase / len of the FETCHED step)
@@ -207,7 +233,7 @@ __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__
         for (int e = 0; e < GG_E; ++e) {
             const int k = a_k(e), kb = b_k(e);
             const bool oka = kbase + k < len && i0 + a_i(e) < M, okb = kbase + kb < len && j0 + b_j(e) < N;
-            if (oka) csum += ra[e];              // colsum problems have no A prologue (checked on the host)
+            if (oka) csum[e & 3] += ra[e];       // colsum problems have no A prologue (checked on the host)
             As[k][a_i(e)] = oka ? ra[e] : 0.f;
             Bs[kb][b_j(e)] = okb ? rb[e] : 0.f;
         }
@@ -318,11 +344,14 @@ __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__
         }
     }
 #endif
-    if (want_cs) {
-        cs[t >> 6][t & 63] = csum;
+    if (want_cs) {                      // thread (t & 15, t >> 4) holds the partial sums of i = 4 (t & 15) + c over its k's
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cs[t >> 4][4 * (t & 15) + c] = csum[c];
         __syncthreads();
         if (t < GG_T && i0 + t < M) {
-            const float v = cs[0][t] + cs[1][t] + cs[2][t] + cs[3][t];
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) v += cs[g][t];
             if (P.accumulate == 2) atomicAdd(P.colsum + i0 + t, v);
             else P.colsum[i0 + t] = P.accumulate ? P.colsum[i0 + t] + v : v;
         }
