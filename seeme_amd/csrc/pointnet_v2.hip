@@ -256,6 +256,11 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
                 if (s + P2_XLA < P2_SLOTS || more) x_load(rx, (s + P2_XLA) % 8, xr[(s + P2_XLA) % (P2_XLA + 1)]);
 #endif
             }
+#ifdef P2_PIN_LOADS
+            // keep the requests HERE: under register pressure the scheduler sinks them towards their use (ISA: input k-blocks
+            // requested 0-40 MFMAs before use instead of 64), which turns the look-ahead into a stall on HBM latency
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 
             if (s == 0) {
                 // (the two rare, branchy pieces of a tile sit here, where only the rings are live: next to the accumulators
