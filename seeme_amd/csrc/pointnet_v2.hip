@@ -83,6 +83,13 @@ __device__ __forceinline__ void p2_atomic_max(float* p, float v) {
     else atomicMin(reinterpret_cast<unsigned int*>(p), __float_as_uint(v));
 }
 
+#ifndef P2_PIN_LOADS
+#define P2_PIN_LOADS 1   // scheduling fence behind a step's requests (measured: 2.08 -> 1.99 ms, and no scratch)
+#endif
+#ifndef P2_SPREAD_ST
+#define P2_SPREAD_ST 0  // 1: the 8 KiB a wave produces per output half leave through LDS, one KiB per step, instead of as one burst
+                        // (measured: 2.05 ms against 1.99 ms for the burst -- a store in every step's queue costs more than the burst)
+#endif
 #ifndef P2_X_AUX
 #define P2_X_AUX 0      // cache-policy bits of the activation loads (bit 1 = non-temporal)
 #endif
@@ -115,6 +122,12 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
     float* const smax = sb1 + P2_H;                                   // [8][256]
     const uint2* const sposf = reinterpret_cast<const uint2*>(smem + P2_RING_BYTES + 2048 + P2_NW * 1024);
     const uint2* const ssc3f = sposf + 32 * 64;
+#if P2_SPREAD_ST
+    // staging of the block output: [wave][8 KiB], written at the end of an output half, drained one KiB per step.  Measured
+    // with cycle stamps: issued as 8 stores at once, an epilogue step took 5.8-7.4 k cycles instead of ~1.6 k -- every CU
+    // reaches its epilogue at about the same time, and 256 x 64 KiB leave for HBM in one burst, twice per tile.
+    uint4* const sout = reinterpret_cast<uint4*>(smem + P2_RING_BYTES + 2048 + P2_NW * 1024 + (FIRST ? 16384 + 8192 : 0)) + (threadIdx.x >> 6) * 512 + (threadIdx.x & 63);
+#endif
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 15, kq = lane >> 4;
     const int row0 = wave * 32;
@@ -221,6 +234,10 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
 #pragma unroll
     for (int i = 0; i < P2_PRE; ++i) af[i] = rl[i * 64];
 
+#if P2_SPREAD_ST
+    __amdgpu_buffer_rsrc_t ro_prev = __builtin_amdgcn_make_buffer_rsrc((unsigned short*)nullptr, 0, 0, 0x00020000);
+    bool pend_prev = false;
+#endif
     for (int t = t0; t < t1; ++t) {
         const int scene = t / a.tiles_x, p0 = (t - scene * a.tiles_x) * P2_MT;
         const int rows_valid = min(P2_MT, a.P - p0);
@@ -235,6 +252,8 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
         f32x4 acc1[8][2];
 #pragma unroll
         for (int s = 0; s < P2_SLOTS; ++s) {
+            // (P2_SPREAD_ST drain: steps 16..23 carry half 0 of this tile, steps 0..7 half 1 of the previous tile; piece j = step % 8
+            // = feature k-block 4 g + j / 2 of point tile j % 2 -- issued behind this step's barrier and requests, below)
             // ---- ring turn: slot s was written one step ago; after the barrier it is readable and the other position is free
             P2_STAMP(0);
 #ifndef P2_ABL_NOBAR
@@ -256,7 +275,27 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
                 if (s + P2_XLA < P2_SLOTS || more) x_load(rx, (s + P2_XLA) % 8, xr[(s + P2_XLA) % (P2_XLA + 1)]);
 #endif
             }
-#ifdef P2_PIN_LOADS
+#if P2_SPREAD_ST
+            {
+                // half 0 is complete at the end of step E0 (15; block_0: 19) and leaves during the steps up to 23; half 1 is
+                // complete at the end of step 23 and leaves during steps 0..7 of the next tile
+                constexpr int E0 = FIRST ? 19 : 15, PPS = 8 / (P2_SLOTS - 1 - E0);      // pieces per step of half 0
+                if (s > E0) {
+#pragma unroll
+                    for (int u = 0; u < PPS; ++u) {
+                        const int j = (s - E0 - 1) * PPS + u;
+                        const uint4 v = sout[j * 64];
+                        __builtin_amdgcn_raw_buffer_store_b128(p2_u32x4{v.x, v.y, v.z, v.w}, ro, f_lane,
+                                                               (unsigned)((j >> 1) * 1024 + (j & 1) * 8192), P2_ST_AUX);
+                    }
+                } else if (s < 8 && pend_prev) {
+                    const uint4 v = sout[s * 64];
+                    __builtin_amdgcn_raw_buffer_store_b128(p2_u32x4{v.x, v.y, v.z, v.w}, ro_prev, f_lane,
+                                                           (unsigned)((4 + (s >> 1)) * 1024 + (s & 1) * 8192), P2_ST_AUX);
+                }
+            }
+#endif
+#if P2_PIN_LOADS
             // keep the requests HERE: under register pressure the scheduler sinks them towards their use (ISA: input k-blocks
             // requested 0-40 MFMAs before use instead of 64), which turns the look-ahead into a stall on HBM latency
             __builtin_amdgcn_sched_barrier(0);
@@ -410,7 +449,9 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
 #pragma unroll
                             for (int mt = 0; mt < 2; ++mt) {
                                 const f32x4 u = acc1[2 * kl][mt], v = acc1[2 * kl + 1][mt];
-#ifndef P2_ABL_NOSTORE
+#if P2_SPREAD_ST
+                                sout[(2 * kl + mt) * 64] = make_uint4(p2_pack(u[0], u[1]), p2_pack(u[2], u[3]), p2_pack(v[0], v[1]), p2_pack(v[2], v[3]));
+#elif !defined(P2_ABL_NOSTORE)
                                 __builtin_amdgcn_raw_buffer_store_b128(p2_u32x4{p2_pack(u[0], u[1]), p2_pack(u[2], u[3]), p2_pack(v[0], v[1]), p2_pack(v[2], v[3])},
                                                                        ro, f_lane, (unsigned)((4 * g + kl) * 1024 + mt * 8192), P2_ST_AUX);
 #endif
@@ -452,7 +493,20 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
             }
             P2_STAMP(2);
         }
+#if P2_SPREAD_ST
+        ro_prev = ro;
+        pend_prev = has_out;
+#endif
     }
+#if P2_SPREAD_ST
+    if (pend_prev) {                       // half 1 of the last tile
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint4 v = sout[j * 64];
+            __builtin_amdgcn_raw_buffer_store_b128(p2_u32x4{v.x, v.y, v.z, v.w}, ro_prev, f_lane, (unsigned)((4 + (j >> 1)) * 1024 + (j & 1) * 8192), P2_ST_AUX);
+        }
+    }
+#endif
     __syncthreads();
     if (tid < P2_H && prev_scene >= 0) {
         float m = smax[tid];
@@ -464,7 +518,7 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
 
 // launch helper used by seeme_pointnet_encode_bf16 (pointnet_bf16.hip)
 int seeme_pn_block2_launch(bool first, const PnBlock2Args& a, int n_cu, hipStream_t st) {
-    const size_t lds = P2_RING_BYTES + 2048 + P2_NW * 1024 + (first ? 16384 + 8192 : 0);
+    const size_t lds = P2_RING_BYTES + 2048 + P2_NW * 1024 + (first ? 16384 + 8192 : 0) + (P2_SPREAD_ST ? P2_NW * 8192 : 0);
     const int per_cu = 8 / P2_NW;
     const dim3 grid((unsigned)(a.n_tiles < n_cu * per_cu ? a.n_tiles : n_cu * per_cu));
     if (first) {
