@@ -1,10 +1,11 @@
 # Round-2 evidence run (one gpurun call): tests, bench lines, steady-state kernel stats (rocprofv3 --kernel-trace), the
 # per-CU stream probe, PointNet PMC counters.  Summaries land in gpurun_out/r02/ (copied to profiles/ by hand).
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r02 && O=gpurun_out/r02
+cd $GRAFT_REPO_ROOT && T=${1:-r02} && mkdir -p gpurun_out/$T && O=gpurun_out/$T
 timeout -k 10 900 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
 timeout -k 10 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
 timeout -k 10 300 python bench.py --weights fp32 --vae fp32 --no-cpu-baseline > $O/bench_fp32.json 2>/dev/null
+timeout -k 10 300 python bench.py --batch 256 --no-cpu-baseline > $O/bench_B256.json 2>/dev/null
 timeout -k 10 300 python bench.py --mode train --steps 20 > $O/bench_train_scene.json 2>/dev/null
 timeout -k 10 300 python bench.py --mode train --train-config gimo --steps 20 > $O/bench_train_gimo.json 2>/dev/null
 SEEME_BENCH_BACKEND=gloo SEEME_BENCH_DEVICE=0 timeout -k 10 300 python bench.py --gpus 2 --no-cpu-baseline > $O/bench_gloo2.json 2>/dev/null
@@ -38,8 +39,8 @@ def steady(tag, marker, skip, steps, out):
             w.writerow([k, v[0], round(v[0] / steps, 2), round(v[1], 1), round(v[1] / v[0], 2), round(100 * v[1] / tot, 2)])
         w.writerow(["# steady-state window", f"{steps} steps", f"launches/step {sum(v[0] for v in agg.values()) / steps:.1f}", f"kernel time/step {tot / steps:.1f} us", f"wall/step {(t1 - t0) / 1e3 / steps:.1f} us", ""])
     print(tag, "launches/step", round(sum(v[0] for v in agg.values()) / steps, 1), "kernel us/step", round(tot / steps, 1), "wall us/step", round((t1 - t0) / 1e3 / steps, 1))
-steady("kt_s", "k_den_sample", 3, 10, "gpurun_out/r02/kernel_stats_sample_steady.csv")
-steady("kt_t", "k_adamw", 3, 10, "gpurun_out/r02/kernel_stats_train_steady.csv")
+steady("kt_s", "k_den_sample", 3, 10, "gpurun_out/$T/kernel_stats_sample_steady.csv")
+steady("kt_t", "k_adamw", 3, 10, "gpurun_out/$T/kernel_stats_train_steady.csv")
 PY
 rm -rf gpurun_out/kt_s gpurun_out/kt_t
 timeout -k 10 400 bash scripts/gpu_pmc_pn2.sh > $O/pmc_pointnet_v2.log 2>&1; rm -rf gpurun_out/pmc_pnb1 gpurun_out/pmc_pnb2 gpurun_out/pmc_pnb3 gpurun_out/pmc_pnb*.log
