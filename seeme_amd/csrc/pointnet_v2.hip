@@ -99,13 +99,13 @@ __device__ __forceinline__ void p2_atomic_max(float* p, float v) {
 #ifdef P2_DBG_TIMES
 // debug build only (scripts/pn2_times.py): cycle stamps of every wave of one workgroup around the barrier and the MFMA
 // section of every step of its fourth tile
-__device__ unsigned long long p2_dbg[8][P2_SLOTS][3];
+__device__ unsigned long long p2_dbg[8][P2_SLOTS][6];
 #ifndef P2_DBG_FIRST
 #define P2_DBG_FIRST 0
 #endif
 #define P2_STAMP(i) do { if (FIRST == (P2_DBG_FIRST != 0) && a.out != nullptr && blockIdx.x == 40 && t == t0 + 3 && lane == 0) p2_dbg[wave][s][i] = __builtin_readcyclecounter(); } while (0)
 extern "C" int seeme_debug_pn2_times(unsigned long long* host) {
-    SEEME_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(p2_dbg), sizeof(unsigned long long) * 8 * P2_SLOTS * 3));
+    SEEME_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(p2_dbg), sizeof(unsigned long long) * 8 * P2_SLOTS * 6));
     return 0;
 }
 #else
@@ -432,6 +432,7 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
 #else
                 if (q == PER_HALF - 1) {
 #endif
+                    P2_STAMP(3);
                     if (FIRST) {
                         // folded shortcut (3 -> 256, bias included) on the matrix cores, into the same accumulator
 #pragma unroll
@@ -457,6 +458,7 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
 #endif
                             }
                     }
+                    P2_STAMP(4);
                     // Column max over the wave's 32 points, four feature tiles (16 values per lane) at a time: reduce-scatter over
                     // the 16 lanes of a DPP row (15 exchanges); lane r ends with value r = 4 t + i of the group: feature
                     // 16 (8 g + 4 gl + t) + 4 kq + i
