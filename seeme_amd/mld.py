@@ -9,11 +9,13 @@ What runs where
     helpers and renorm run in libseeme_hip.so (HIP kernels for gfx950).
   * Stage-2 *training*: the frozen encoders and the denoiser forward + hand-written backward
     (``denoiser_train.py``: ``k_den_sample`` with saves, ``k_den_bwd``, ``seeme_den_wgrad``) are HIP; the table builders
-    around the chain are batched torch ops carried by autograd; every gradient lives in one flat buffer
+    around the chain (rsample, add_noise, time MLP, output_scene, condition / time tables) are hand-written too
+    (``stage2_glue.py``: one autograd node for the whole step); every gradient lives in one flat buffer
     (``distributed.GradBucket``) that is all-reduced in place and consumed by the one-launch AdamW.  More than one
     attention head falls back to the autograd twin (``denoiser_autograd.py``).
-  * Stage-1 (VAE) training runs through differentiable twins of the VAE and the SMPL joint regressor
-    (``vae_autograd.py``) on PyTorch-ROCm autograd; evaluation of that stage is HIP.
+  * Stage-1 (VAE) *training*: hand-written HIP forward-with-saves / backward of the encoder and the decoder
+    (``vae_train.py``: grouped fp32 GEMMs + LayerNorm / softmax / GELU / dropout kernels) and of the SMPL joint regressor
+    (``smpl._JointsAA``); the differentiable twins (``vae_autograd.py``) are the fallback; evaluation of that stage is HIP.
   * Only the live flows are implemented; the reference's dead code (``forward`` calling the undefined
     ``feats2joints``, t2m_eval, the ``save_for_edo`` debug dump -- SURVEY.md App. D) is not reproduced:
     ``forward``/``sample`` = what ``ego_eval`` really does (condition -> reverse diffusion -> decode).

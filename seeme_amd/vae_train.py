@@ -414,7 +414,11 @@ class VaeTrainer:
         k = (dec, B, T, drop)
         p = self.plans.get(k)
         if p is None or p.busy:           # busy: a second forward before the first one's backward keeps that one's saved tensors
+            if len(self.plans) >= 8:      # a plan holds every saved activation of its shape (B=64, T=196: ~1.5 GB): keep the recent ones
+                for old in [q for q, v in self.plans.items() if not v.busy][: len(self.plans) - 7]:
+                    del self.plans[old]
             p = _StackPlan(self.vae, dec, B, T, drop)
+            self.plans.pop(k, None)
             self.plans[k] = p
         return p
 
