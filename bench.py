@@ -248,7 +248,9 @@ def train_mode(args, dev, rank, world, backend, dist_on):
     from seeme_amd.weights_recipe import load_recipe_
     from seeme_amd import distributed as D
     which = args.train_config or ("scene" if world == 1 else "gimo")
-    cfgfile = {"scene": "config_mld_scene.yaml", "gimo": "config_mld_gimo.yaml", "egobody": "config_mld_egobody.yaml"}[which]
+    cfgfile = {"scene": "config_mld_scene.yaml", "gimo": "config_mld_gimo.yaml", "egobody": "config_mld_egobody.yaml",
+               "vae": "config_vae_egobody.yaml"}[which]
+    stage1 = which == "vae"
     cfg = parse_config(os.path.join(REPO, "configs", cfgfile))
     cfg.TRAIN.FROZEN_VAE_PRECISION = args.vae
     cfg.TRAIN.SCENE_PRECISION = "bf16"
@@ -257,7 +259,7 @@ def train_mode(args, dev, rank, world, backend, dist_on):
     dm = SyntheticEgoDataModule(nfeats=nfeats, T=T_FRAMES, n_points=P, seed=1234, device=dev)
     model = MLD(cfg, dm, smpl_model=SMPL.synthetic(1234))
     load_recipe_(model.vae), load_recipe_(model.denoiser)
-    with_scene = "scene" in cfg.model.condition
+    with_scene = "scene" in cfg.model.condition and not stage1
     if with_scene:
         load_recipe_(model.proscene.scene_enc)
     model = model.to(dev).train()
@@ -266,6 +268,8 @@ def train_mode(args, dev, rank, world, backend, dist_on):
     batches = [dm.batch(B, idx=2 * rank + i, with_scene=with_scene) for i in range(2)]     # resident in HBM
     ev = lambda: torch.cuda.Event(enable_timing=True)
     pn_ev = []
+    if args.graph and stage1:
+        raise SystemExit("--graph: stage-2 training only")
     if args.graph:
         replay = model.capture_training_step(batches[0])
         step = lambda i, e=None: replay(batches[i % 2])
@@ -299,13 +303,15 @@ def train_mode(args, dev, rank, world, backend, dist_on):
     if with_scene:
         model.proscene.scene_enc.timing_events = None
     res = {
-        "metric": "stage-2 training seqs/sec (T=196, B=%d/GPU%s)" % (B, ", %d-point scenes" % P if with_scene else ""),
+        "metric": ("stage-1 (VAE) training seqs/sec (T=196, B=%d/GPU)" % B) if stage1 else
+                  "stage-2 training seqs/sec (T=196, B=%d/GPU%s)" % (B, ", %d-point scenes" % P if with_scene else ""),
         "value": round(world * B * args.steps / dt, 2), "unit": "seqs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": f"f32 (denoiser forward/backward, AdamW; frozen encoders: bf16 PointNet MFMA operands, {args.vae} VAE operands)",
+        "dtype": "f32 (VAE + SMPL forward / backward on fp32 MFMA, AdamW)" if stage1 else
+                 f"f32 (denoiser forward/backward, AdamW; frozen encoders: bf16 PointNet MFMA operands, {args.vae} VAE operands)",
         "data": "synthetic",
-        "config": {"workload": f"{cfgfile}: stage-2 training step, condition {list(cfg.model.condition)}, B={B}/GPU, T=196, "
+        "config": {"workload": f"{cfgfile}: stage-{1 if stage1 else 2} training step, condition {list(cfg.model.condition)}, B={B}/GPU, T=196, "
                                f"nfeats={nfeats}" + (f", {P}-point scenes" if with_scene else "") + ", random-init recipe weights",
                    "batch_per_gpu": B, "global_batch": B * world, "seq_len": T_FRAMES,
                    "parallelism": f"dp{world} (one in-place all-reduce of the flat fp32 gradient buffer per step)"
@@ -317,6 +323,17 @@ def train_mode(args, dev, rank, world, backend, dist_on):
     if not args.graph:
         ph = lambda a, b: round(float(np.mean([e[a].elapsed_time(e[b]) for e in evs])), 4)
         res["phases_ms"] = {"backward": ph(0, 1), "allreduce": ph(1, 2), "adamw": ph(2, 3)}
+        if stage1:
+            # GEMM work of the step: per sequence and layer QKV + Q K^T + P V + out_proj + FFN, 5 encoder layers on T + 2 tokens and 5
+            # decoder layers on T, skip linears, embedding / final projection; forward + data gradient + weight gradient = 3 x forward
+            def fwd(S):
+                return 5 * (2 * S * 256 * 768 + 2 * 2 * S * S * 256 + 2 * S * 256 * 256 + 2 * 2 * S * 256 * 128) + 2 * 2 * S * 512 * 256
+            flops = 3.0 * B * (fwd(T_FRAMES + 2) + fwd(T_FRAMES) + 2 * 2 * T_FRAMES * nfeats * 256)
+            ms = dt / args.steps * 1e3
+            ach = flops / (ms * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": "k_gg (grouped fp32 GEMM on v_mfma_f32_32x32x2_f32): every GEMM of the VAE forward / "
+                               "backward; priced over the WHOLE step", "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s",
+                               "frac": round(ach / 157.3, 4), "traffic": None, "ms_per_launch": round(ms, 4), "gemm_flops_per_step": flops}
         if with_scene:
             pn_ms = float(np.mean([e[4].elapsed_time(e[5]) for e in evs]))
             exe, refg = pointnet_flops(B, P)
@@ -349,7 +366,7 @@ def main():
                          "host cost per pass ~15 us instead of ~2.5 ms of Python")
     ap.add_argument("--mode", default="sample", choices=["sample", "train"],
                     help="sample = the headline metric (BASELINE configs[1]); train = the stage-2 training step (configs[2] / configs[3])")
-    ap.add_argument("--train-config", default=None, choices=["scene", "gimo", "egobody"],
+    ap.add_argument("--train-config", default=None, choices=["scene", "gimo", "egobody", "vae"],
                     help="--mode train: scene = scene + interactee (configs[2], default at 1 GPU), gimo = config_mld_gimo scene-only "
                          "(configs[3], default at N > 1), egobody = interactee only")
     ap.add_argument("--points", type=int, default=20000, help="--mode train: points per scene cloud")

@@ -524,11 +524,13 @@ def test_vae_hip_training_dropout_matches_twin_with_same_masks(dev):
      {"n_gpus": 1}),
     (["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity-check", "--scheduler", "ddpm", "--batch", "8"],
      {"n_gpus": 1}),
+    (["--steps", "2", "--warmup", "1", "--mode", "train", "--train-config", "vae", "--batch", "8"],
+     {"metric": "stage-1 (VAE) training seqs/sec (T=196, B=8/GPU)"}),
 ])
 def test_bench_modes_emit_the_contract_line(dev, argv, checks):
     """bench.py as the driver runs it (a child process, one JSON line on stdout): the --streams / --graph sampling mode (each pass
-    replayed as a hipGraph, two batches in flight), the stage-2 training mode on the GIMO configuration, and the 1000-step DDPM
-    configuration -- every line carries the contract's fields, a roofline object and a positive value."""
+    replayed as a hipGraph, two batches in flight), the stage-2 training mode on the GIMO configuration, the 1000-step DDPM
+    configuration and the stage-1 (VAE) training mode -- every line carries the contract's fields, a roofline object and a positive value."""
     import json
     import subprocess
     import sys

@@ -357,3 +357,24 @@ def test_pointnet_v2_stream_packing_emulated():
         got = (pn.fc_c.weight @ torch.relu(pooled) + pn.fc_c.bias).numpy()
     want = O.pointnet_forward(recipe_state_dict(shapes.pointnet_shapes()), pts.numpy()[None])[0]
     assert rel_err(got, want) < 3e-2, rel_err(got, want)
+
+
+def test_grouped_gemm_descriptor_layout_and_tiling():
+    """The ctypes mirror of SeemeGemmProblem has the library's size (the descriptor tables are byte images built on the host),
+    and _Group lays the 64 x 64 tiles of its problems out back to back, batched members included."""
+    import ctypes as C
+    from seeme_amd import _lib as L
+    from seeme_amd.stage2_glue import _prob, _tiles
+    assert C.sizeof(L.GemmProblem) == L.lib().seeme_gemm_problem_bytes()
+    assert _tiles(64, 64) == (1, 1) and _tiles(65, 130) == (6, 3) and _tiles(198, 198) == (16, 4)
+    p = _prob([1000], [2000], [256], [1], [1], 256, 256, 3000, 768, 198, 768, bias=4000)
+    q = _prob([1000], [2000], [198], [198], [256], 1, 1, 5000, 768, 198, 256, nbatch=7, bstrides=(198 * 198, 198 * 256, 198 * 768),
+              accumulate=2, colsum=6000)
+    assert (p.nseg, p.seg_len[0], p.a_rs, p.b_cs, p.ldc, p.M, p.N, p.nbatch) == (1, 256, 256, 256, 768, 198, 768, 1)
+    assert (q.a_ks[0], q.b_ks[0], q.accumulate, q.nbatch, q.a_bstride, q.c_bstride) == (198, 256, 2, 7, 198 * 198, 198 * 768)
+    t0 = 0
+    for pr in (p, q):                                      # what _Group does before it uploads the table
+        n, tn = _tiles(pr.M, pr.N)
+        pr.tile0, pr.tiles_n = t0, tn
+        t0 += n * max(1, pr.nbatch)
+    assert (p.tile0, p.tiles_n, q.tile0, q.tiles_n, t0) == (0, 12, 48, 4, 48 + 16 * 7)
