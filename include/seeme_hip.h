@@ -201,7 +201,11 @@ typedef struct {
     float* save;           /* training forward only (steps == 1, no CFG, unfolded fp32 image, query GEMV kept): [B, SEEME_DEN_SAVE_FLOATS]
                             * intermediates for seeme_denoiser_backward (seeme_amd/csrc/den_train.h); NULL otherwise */
     int force_query;       /* 1: keep the ca_block query / proj_out GEMVs even for one condition token (differentiable path) */
+    const unsigned char* drop;   /* training forward only (with save): dropout keep-masks [B, SEEME_DEN_DROP_BYTES] of the MD layers'
+                                  * nn.Dropout sites in training mode (layout csrc/den_train.h DM_*), or NULL (eval arithmetic) */
+    float drop_scale;      /* 1 / (1 - p) */
 } SeemeSampleArgs;
+#define SEEME_DEN_DROP_BYTES 10960
 
 int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeSampleArgs* a, void* stream);
 
@@ -220,6 +224,10 @@ int seeme_den_train_pack(const float* const* mats, float* img_f, float* img_b, c
 int seeme_denoiser_backward(const SeemeDenoiserWeights* w, const void* img_bwd, int B, int N, const float* save,
                             const float* ctab, const float* ttab, const int32_t* trow, const float* dout,
                             float* gout, float* dctab, float* dttab, void* stream);
+/* The same with the dropout keep-masks the forward was given (SeemeSampleArgs.drop / drop_scale). */
+int seeme_denoiser_backward_drop(const SeemeDenoiserWeights* w, const void* img_bwd, int B, int N, const float* save,
+                                 const float* ctab, const float* ttab, const int32_t* trow, const float* dout,
+                                 float* gout, float* dctab, float* dttab, const unsigned char* drop, float drop_scale, void* stream);
 
 /* Offsets of the packed weight image (30 per layer x 5, then pe0, fnw, fnb, wg_total, vp_total). */
 int seeme_den_layout(int ff_sa, int ff, int64_t* out, int cap);

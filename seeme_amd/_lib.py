@@ -84,7 +84,7 @@ class DenoiserWeights(C.Structure):
 class SampleArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("N", C.c_int), ("steps", C.c_int), ("sched", C.c_int), ("cfg", C.c_int),
                 ("guidance_scale", C.c_float), ("latents", fp), ("ctab", fp), ("ttab", fp), ("trow", fp),
-                ("trow_per_sample", C.c_int), ("coef", fp), ("noise", fp), ("out", fp), ("catab", fp), ("save", fp), ("force_query", C.c_int)]
+                ("trow_per_sample", C.c_int), ("coef", fp), ("noise", fp), ("out", fp), ("catab", fp), ("save", fp), ("force_query", C.c_int), ("drop", fp), ("drop_scale", C.c_float)]
 
 
 class SmplModel(C.Structure):
@@ -166,6 +166,7 @@ _SIGNATURES = {
     "seeme_den_train_layout": (C.c_int, [C.POINTER(C.c_int64), C.c_int]),
     "seeme_den_train_pack": (C.c_int, [fp, fp, fp, fp, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.c_int, fp, fp]),
     "seeme_denoiser_backward": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp]),
+    "seeme_denoiser_backward_drop": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_float, fp]),
     "seeme_den_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "seeme_den_wgrad": (C.c_int, [fp, C.c_int, C.c_int, fp, C.c_int, fp, fp]),
     "seeme_adamw_step": (C.c_int, [fp, C.c_int, fp, fp, fp, fp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,

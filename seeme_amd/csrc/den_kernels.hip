@@ -633,6 +633,13 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     // query-GEMV variant is differentiable (the folds merge parameters), and only it carries the stores
     constexpr bool SAVE = CAQ && !FOLD && MS == 1;
     float* const sv0 = (SAVE && A.save != nullptr && epi) ? A.save + (size_t)den_lat_index<MS>(A, b, es) * DT_TOTAL : nullptr;
+    // training-mode dropout (keep-masks drawn by the host, one block per sample): only with the saving forward
+    const unsigned char* const dm0 = (SAVE && sv0 && A.drop != nullptr) ? A.drop + (size_t)den_lat_index<MS>(A, b, es) * DM_TOTAL : nullptr;
+    const float dsc = A.drop_scale;
+    auto drop4 = [&](float4 v, const unsigned char* m) {          // m: this lane's 4 mask bytes
+        const uchar4 k = *reinterpret_cast<const uchar4*>(m);
+        return make_float4(k.x ? v.x * dsc : 0.f, k.y ? v.y * dsc : 0.f, k.z ? v.z * dsc : 0.f, k.w ? v.w * dsc : 0.f);
+    };
     float* const keep = KEEP + es * 768 + 4 * lane;   // [0] latent, [256] layer-0 output, [512] layer-1 output
     const int bl = den_lat_index<MS>(A, b, es);          // this epilogue wave's row of latents / noise / out
     float4 xr = ld4(A.latents + (size_t)bl * 256 + 4 * lane);
@@ -688,6 +695,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             const float* CTS = TTS + STG_TT;                 // [MS][N][1024] condition K|V (sa 512 | ca 512)
             const float* CT = CTS + es * N * 1024;
             float* const sv = sv0 ? sv0 + l * DT_LAYER : nullptr;
+            const unsigned char* const dm = dm0 ? dm0 + l * DM_LAYER : nullptr;
             const float* CA_ADD = CTS + MS * N * 1024 + es * 256;   // (one condition token) tabulated ca_block term
             // offsets inside VP (relative to skip_b)
             const float* v_skip_b = VP;
@@ -739,11 +747,13 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
 #pragma unroll
                 for (int j = 0; j < DEN_MAXTOK - 2; ++j) if (j < N) { sc[1 + j] = fast_exp(sc[1 + j] - mx); sum += sc[1 + j]; }
                 const float inv = fast_rcp(sum);
-                float4 att = f4_scale(v0, e0 * inv);
+                // (dropout on the attention weights: the saved probabilities stay the un-dropped ones, the backward re-applies the mask)
+                auto pk = [&](int j) { return (SAVE && dm) ? (dm[DM_P + j] ? dsc : 0.f) : 1.f; };
+                float4 att = f4_scale(v0, e0 * inv * pk(0));
 #pragma unroll
                 for (int j = 0; j < DEN_MAXTOK - 2; ++j)
-                    if (j < N) att = f4_fma(sc[1 + j] * inv, ld4(CT + j * 1024 + 256 + 4 * lane), att);
-                att = f4_fma(et * inv, ld4(TTS + 256 + 4 * lane), att);
+                    if (j < N) att = f4_fma(sc[1 + j] * inv * pk(1 + j), ld4(CT + j * 1024 + 256 + 4 * lane), att);
+                att = f4_fma(et * inv * pk(1 + N), ld4(TTS + 256 + 4 * lane), att);
                 if (SAVE && sv) {
                     st4(sv + DT_A + 4 * lane, att);
                     if (lane == 0) {
@@ -765,7 +775,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                 // ---- out_proj + residual + norm1
                 gemv_stream<WT, V, MS, G_OUTP, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
                 if (epi) {
-                    const float4 v = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_out_b + 4 * lane)));
+                    float4 o = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_out_b + 4 * lane));
+                    if (SAVE && dm) o = drop4(o, dm + DM_1 + 4 * lane);
+                    const float4 v = f4_add(xr, o);
                     float4 xh; float rs;
                     xr = wave_ln_stats(v, v_n1w, v_n1b, lane, xh, rs);
                     if (SAVE && sv) { st4(sv + DT_XH1 + 4 * lane, xh); if (lane == 0) sv[DT_RS + 0] = rs; }
@@ -779,7 +791,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
 #pragma unroll
                 for (int j = 0; j < FF_SA / 256; ++j) {
                     const float4 h = f4_add(gemv_out<WT, MS, G_L1>(PART, es, 256 * j, lane), ld4(v_l1b + 256 * j + 4 * lane));
-                    const float4 hr = make_float4(fmaxf(h.x, 0.f), fmaxf(h.y, 0.f), fmaxf(h.z, 0.f), fmaxf(h.w, 0.f));
+                    float4 hr = make_float4(fmaxf(h.x, 0.f), fmaxf(h.y, 0.f), fmaxf(h.z, 0.f), fmaxf(h.w, 0.f));
+                    if (SAVE && dm) hr = drop4(hr, dm + DM_H + 256 * j + 4 * lane);
                     if (SAVE && sv) st4(sv + DT_H + 256 * j + 4 * lane, hr);
                     put_x<WT, MS>(XB, es, 256 * j, lane, hr);
                 }
@@ -788,7 +801,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             // ---- linear2 + residual + norm2, then ca_block (mdiff_transformer.py:219-239, 152-163)
             gemv_stream<WT, V, MS, G_L2, false>(ring, tid, wg, mo, nskip, xin, PART, epi);
             if (epi) {
-                const float4 v = f4_add(xr, f4_add(part256<WT, MS>(PART, es, lane), ld4(v_l2b + 4 * lane)));
+                float4 o2 = f4_add(part256<WT, MS>(PART, es, lane), ld4(v_l2b + 4 * lane));
+                if (SAVE && dm) o2 = drop4(o2, dm + DM_2 + 4 * lane);
+                const float4 v = f4_add(xr, o2);
                 float4 xh2; float rs2;
                 xr = wave_ln_stats(v, v_n2w, v_n2b, lane, xh2, rs2);
                 if constexpr (CAQ) {
@@ -846,7 +861,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                         st4(sv + DT_QC + 4 * lane, qc); st4(sv + DT_XHY + 4 * lane, xhy); st4(sv + DT_U + 4 * lane, hh);
                         if (lane == 0) sv[DT_RS + 3] = rsy;
                     }
-                    put_x<WT, MS>(XB, es, 0, lane, f4_silu(hh));
+                    put_x<WT, MS>(XB, es, 0, lane, (SAVE && dm) ? drop4(f4_silu(hh), dm + DM_C + 4 * lane) : f4_silu(hh));
                 }
                 __syncthreads(); DEN_DBG(0);
                 // ---- proj_out.out_layers + residual
@@ -867,7 +882,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
             if (epi && lane < FF_D / 4) {
                 const float4 g = f4_add(gemv_out<WT, MS, G_F1>(PART, es, 0, lane), ld4(v_f1b + 4 * lane));
                 if (SAVE && sv) st4(sv + DT_Z1 + 4 * lane, g);
-                put_x<WT, MS>(XB, es, 0, lane, make_float4(fast_gelu(g.x), fast_gelu(g.y), fast_gelu(g.z), fast_gelu(g.w)));
+                const float4 gg = make_float4(fast_gelu(g.x), fast_gelu(g.y), fast_gelu(g.z), fast_gelu(g.w));
+                put_x<WT, MS>(XB, es, 0, lane, (SAVE && dm) ? drop4(gg, dm + DM_F + 4 * lane) : gg);
             }
             __syncthreads(); DEN_DBG(0);
             // ---- ffn.linear2 -> AdaLN
@@ -879,7 +895,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
                 float4 xhy2; float rsy2;
                 const float4 hh = f4_adaln(wave_ln_stats(y2, v_fsnw, v_fsnb, lane, xhy2, rsy2), ld4(TTS + 1024 + 4 * lane), ld4(TTS + 1280 + 4 * lane));
                 if (SAVE && sv) { st4(sv + DT_XHY2 + 4 * lane, xhy2); st4(sv + DT_U2 + 4 * lane, hh); if (lane == 0) sv[DT_RS + 4] = rsy2; }
-                put_x<WT, MS>(XB, es, 0, lane, f4_silu(hh));
+                put_x<WT, MS>(XB, es, 0, lane, (SAVE && dm) ? drop4(f4_silu(hh), dm + DM_O + 4 * lane) : f4_silu(hh));
             }
             __syncthreads(); DEN_DBG(0);
             // ---- ffn.proj_out.out_layers + residual; its epilogue also prepares the input of the next layer

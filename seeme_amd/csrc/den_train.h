@@ -51,3 +51,16 @@
 #define DB_FIN     (5 * DB_LAYER)         // encoder.norm: dw 256 | db 256
 #define DB_DX0     (5 * DB_LAYER + 512)   // gradient of the first layer's input (sample + query_pos)
 #define DB_TOTAL   (5 * DB_LAYER + 768)
+
+// ---- dropout keep-masks of the training forward / backward (bytes, per sample and layer; nn.Dropout sites of the reference's
+// MD layer in training mode: mdiff_transformer.py:137-165 (StylizationBlock.out_layers), :241-254 (FFN), cross_attention.py:264-273
+// (sa_block: attention weights of token 0's row, dropout1, the FFN's inner dropout, dropout2))
+#define DM_P      0        // attention weights of token 0: [0] self, [1..N] condition, [N+1] time      8
+#define DM_1      8        // sa_block.dropout1 (out_proj output)                          256
+#define DM_H      264      // sa_block.dropout (relu(linear1))                             1024
+#define DM_2      1288     // sa_block.dropout2 (linear2 output)                           256
+#define DM_C      1544     // ca_block.proj_out.out_layers dropout (silu(u))               256
+#define DM_F      1800     // ffn.dropout (gelu(linear1))                                  128
+#define DM_O      1928     // ffn.proj_out.out_layers dropout (silu(u2))                   256
+#define DM_LAYER  2192
+#define DM_TOTAL  (5 * DM_LAYER)

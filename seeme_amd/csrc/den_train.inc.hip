@@ -106,6 +106,8 @@ struct DenBwdArgs {
     const float* vp; DenLayout lay;    // vector params (LayerNorm weights) and their offsets
     int B, N;
     const float* save;                 // [B, DT_TOTAL] from the forward
+    const unsigned char* drop;         // [B, DM_TOTAL] dropout keep-masks of the forward, or NULL
+    float drop_scale;
     const float* ctab; const float* ttab; const int32_t* trow;   // the forward's tables (per-sample rows)
     const float* dout;                 // [B,256] gradient of the model output
     float* gout;                       // [B, DB_TOTAL]
@@ -167,6 +169,12 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_bwd(const DenBwdArgs a) {
     float* __restrict__ dtt = a.dttab + (size_t)b * SEEME_TROW;
     const float* __restrict__ vp = a.vp;
     const float scale = 1.f / 16.f;                             // one head of 256 dims
+    const unsigned char* const dm0 = a.drop ? a.drop + (size_t)b * DM_TOTAL : nullptr;
+    const float dsc = a.drop_scale;
+    auto drop4 = [&](float4 v, const unsigned char* m) {        // the forward's dropout mask on a gradient / a saved activation
+        const uchar4 k = *reinterpret_cast<const uchar4*>(m);
+        return make_float4(k.x ? v.x * dsc : 0.f, k.y ? v.y * dsc : 0.f, k.z ? v.z * dsc : 0.f, k.w ? v.w * dsc : 0.f);
+    };
 
     // ---- encoder.norm
     float4 dx;
@@ -183,17 +191,20 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_bwd(const DenBwdArgs a) {
         const float* __restrict__ sv = sv0 + l * DT_LAYER;
         float* __restrict__ go = go0 + (size_t)l * DB_LAYER;
         float* const gw = w0 ? go : nullptr;                     // (writes by wave 0 only)
+        const unsigned char* const dm = dm0 ? dm0 + l * DM_LAYER : nullptr;
         if (l == 1) dx = f4_add(dx, dsk1);
         if (l == 0) dx = f4_add(dx, dsk0);
 
         // ================= ffn: x4 = x3 + Wfo silu(u2) + b
         const float4 u2 = ld4(sv + DT_U2 + 4 * lane);
-        if (gw) { st4(gw + DB_X_FO + 4 * lane, f4_silu(u2)); st4(gw + DB_Y_FO + 4 * lane, dx); st4(XB + 4 * lane, dx); }
+        if (gw) { st4(gw + DB_X_FO + 4 * lane, dm ? drop4(f4_silu(u2), dm + DM_O + 4 * lane) : f4_silu(u2)); st4(gw + DB_Y_FO + 4 * lane, dx); st4(XB + 4 * lane, dx); }
         __syncthreads();
         gemv_plain<GB_FO>(tid, wb, mb[0], XB, PART);
         float4 dy2;
         {
-            const float4 du2 = f4_mul(part_sum<1, GS<WF32, GB_FO>::KS, 256>(PART, 0, 0, lane), f4_dsilu(u2));
+            float4 ds2 = part_sum<1, GS<WF32, GB_FO>::KS, 256>(PART, 0, 0, lane);
+            if (dm) ds2 = drop4(ds2, dm + DM_O + 4 * lane);
+            const float4 du2 = f4_mul(ds2, f4_dsilu(u2));
             const float4 xh = ld4(sv + DT_XHY2 + 4 * lane);
             const float4 lw = ld4(vp + L.fsnw + 4 * lane), lb = ld4(vp + L.fsnb + 4 * lane);
             const float4 ln = make_float4(xh.x * lw.x + lb.x, xh.y * lw.y + lb.y, xh.z * lw.z + lb.z, xh.w * lw.w + lb.w);
@@ -206,14 +217,18 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_bwd(const DenBwdArgs a) {
         if (lane < 32) z1 = ld4(sv + DT_Z1 + 4 * lane);
         if (gw) {
             st4(gw + DB_Y_F2 + 4 * lane, dy2); st4(XB + 4 * lane, dy2);
-            if (lane < 32) st4(gw + DB_X_F2 + 4 * lane, make_float4(fast_gelu(z1.x), fast_gelu(z1.y), fast_gelu(z1.z), fast_gelu(z1.w)));
+            if (lane < 32) {
+                const float4 gz = make_float4(fast_gelu(z1.x), fast_gelu(z1.y), fast_gelu(z1.z), fast_gelu(z1.w));
+                st4(gw + DB_X_F2 + 4 * lane, dm ? drop4(gz, dm + DM_F + 4 * lane) : gz);
+            }
         }
         __syncthreads();
         gemv_plain<GB_F2>(tid, wb, mb[1], XB, PART);
         {
             float4 dz1 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (lane < 32) {
-                const float4 dg = part_sum<1, GS<WF32, GB_F2>::KS, FF_D>(PART, 0, 0, lane);
+                float4 dg = part_sum<1, GS<WF32, GB_F2>::KS, FF_D>(PART, 0, 0, lane);
+                if (dm) dg = drop4(dg, dm + DM_F + 4 * lane);
                 dz1 = make_float4(dg.x * dgelu(z1.x), dg.y * dgelu(z1.y), dg.z * dgelu(z1.z), dg.w * dgelu(z1.w));
             }
             if (gw) {
@@ -227,12 +242,14 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_bwd(const DenBwdArgs a) {
 
         // ================= ca_block: x3 = x2 + Wpo silu(u) + b,  u = LN(y)(1+sc)+sh,  y = sum_j (qc . kc_j) vv_j
         const float4 u = ld4(sv + DT_U + 4 * lane);
-        if (gw) { st4(gw + DB_X_CAO + 4 * lane, f4_silu(u)); st4(gw + DB_Y_CAO + 4 * lane, dx3); st4(XB + 4 * lane, dx3); }
+        if (gw) { st4(gw + DB_X_CAO + 4 * lane, dm ? drop4(f4_silu(u), dm + DM_C + 4 * lane) : f4_silu(u)); st4(gw + DB_Y_CAO + 4 * lane, dx3); st4(XB + 4 * lane, dx3); }
         __syncthreads();
         gemv_plain<GB_CAO>(tid, wb, mb[3], XB, PART);
         float4 dqq;
         {
-            const float4 du = f4_mul(part_sum<1, GS<WF32, GB_CAO>::KS, 256>(PART, 0, 0, lane), f4_dsilu(u));
+            float4 dsu = part_sum<1, GS<WF32, GB_CAO>::KS, 256>(PART, 0, 0, lane);
+            if (dm) dsu = drop4(dsu, dm + DM_C + 4 * lane);
+            const float4 du = f4_mul(dsu, f4_dsilu(u));
             const float4 xh = ld4(sv + DT_XHY + 4 * lane);
             const float4 lw = ld4(vp + L.csnw + 4 * lane), lb = ld4(vp + L.csnb + 4 * lane);
             const float4 ln = make_float4(xh.x * lw.x + lb.x, xh.y * lw.y + lb.y, xh.z * lw.z + lb.z, xh.w * lw.w + lb.w);
@@ -291,8 +308,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_bwd(const DenBwdArgs a) {
 
         // ================= sa_block tail: x2 = LN2(x1 + W2 relu(W1 x1))
         const float4 dv2 = ln_bwd(dx2, vp + L.n2w, ld4(sv + DT_XH2 + 4 * lane), sv[DT_RS + 1], lane, gw ? gw + DB_LN + 1 * 512 : nullptr);
+        const float4 dv2m = dm ? drop4(dv2, dm + DM_2 + 4 * lane) : dv2;      // through dropout2 into linear2's output
         if (gw) {
-            st4(gw + DB_Y_L2 + 4 * lane, dv2); st4(XB + 4 * lane, dv2);
+            st4(gw + DB_Y_L2 + 4 * lane, dv2m); st4(XB + 4 * lane, dv2m);
 #pragma unroll
             for (int j = 0; j < 4; ++j) st4(gw + DB_X_L2 + 256 * j + 4 * lane, ld4(sv + DT_H + 256 * j + 4 * lane));
         }
@@ -304,7 +322,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_bwd(const DenBwdArgs a) {
             for (int j = 0; j < 4; ++j) {
                 const float4 h = ld4(sv + DT_H + 256 * j + 4 * lane);
                 const float4 dh = part_sum<1, GS<WF32, GB_L2>::KS, FF_SA>(PART, 0, 256 * j, lane);
-                dz[j] = make_float4(h.x > 0.f ? dh.x : 0.f, h.y > 0.f ? dh.y : 0.f, h.z > 0.f ? dh.z : 0.f, h.w > 0.f ? dh.w : 0.f);
+                // (the saved h is relu + dropout: h > 0 means kept and active; a kept element's gradient carries the 1 / (1 - p))
+                const float kf = dm ? dsc : 1.f;
+                dz[j] = make_float4(h.x > 0.f ? dh.x * kf : 0.f, h.y > 0.f ? dh.y * kf : 0.f, h.z > 0.f ? dh.z * kf : 0.f, h.w > 0.f ? dh.w * kf : 0.f);
             }
             __syncthreads();                                   // every wave has read PART before XB / PART are reused
             if (gw) {
@@ -323,29 +343,32 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_bwd(const DenBwdArgs a) {
         const float4 dv1 = ln_bwd(dx1, vp + L.n1w, xh1, sv[DT_RS + 0], lane, gw ? gw + DB_LN : nullptr);
 
         // ================= attention over [x, xf.., emb] (token 0 only): o = Wo sum_j p_j v_j
-        if (gw) { st4(gw + DB_X_OUTP + 4 * lane, ld4(sv + DT_A + 4 * lane)); st4(gw + DB_Y_OUTP + 4 * lane, dv1); st4(XB + 4 * lane, dv1); }
+        const float4 dv1m = dm ? drop4(dv1, dm + DM_1 + 4 * lane) : dv1;      // through dropout1 into out_proj's output
+        if (gw) { st4(gw + DB_X_OUTP + 4 * lane, ld4(sv + DT_A + 4 * lane)); st4(gw + DB_Y_OUTP + 4 * lane, dv1m); st4(XB + 4 * lane, dv1m); }
         __syncthreads();
         gemv_plain<GB_OUTP>(tid, wb, mb[7], XB, PART);
         {
             const float4 da = part_sum<1, GS<WF32, GB_OUTP>::KS, 256>(PART, 0, 0, lane);
             const float4 q = ld4(sv + DT_QKV + 4 * lane), k0 = ld4(sv + DT_QKV + 256 + 4 * lane), v0 = ld4(sv + DT_QKV + 512 + 4 * lane);
             // d p_j = da . v_j ; softmax backward
+            // a = sum_j p_j m_j v_j with the saved (un-dropped) p and the keep factors m_j in {0, 1 / (1 - p)}
             float dp[DEN_MAXTOK], p[DEN_MAXTOK];
-            p[0] = sv[DT_P]; dp[0] = wave_sum(f4_dot(da, v0));
+            auto pk = [&](int j) { return dm ? (dm[DM_P + j] ? dsc : 0.f) : 1.f; };
+            p[0] = sv[DT_P]; dp[0] = wave_sum(f4_dot(da, v0)) * pk(0);
             float dsum = p[0] * dp[0];
 #pragma unroll
             for (int j = 0; j < DEN_MAXTOK - 2; ++j)
                 if (j < N) {
                     p[1 + j] = sv[DT_P + 1 + j];
-                    dp[1 + j] = wave_sum(f4_dot(da, ld4(a.ctab + ((size_t)b * N + j) * SEEME_CROW + l * 512 + 256 + 4 * lane)));
+                    dp[1 + j] = wave_sum(f4_dot(da, ld4(a.ctab + ((size_t)b * N + j) * SEEME_CROW + l * 512 + 256 + 4 * lane))) * pk(1 + j);
                     dsum += p[1 + j] * dp[1 + j];
                 }
             const float pt = sv[DT_P + 1 + N];
-            const float dpt = wave_sum(f4_dot(da, ld4(tt + l * 512 + 256 + 4 * lane)));
+            const float dpt = wave_sum(f4_dot(da, ld4(tt + l * 512 + 256 + 4 * lane))) * pk(1 + N);
             dsum += pt * dpt;
             const float ds0 = p[0] * (dp[0] - dsum) * scale;
             float4 dq = f4_scale(k0, ds0);
-            const float4 dk0 = f4_scale(q, ds0), dv0 = f4_scale(da, p[0]);
+            const float4 dk0 = f4_scale(q, ds0), dv0 = f4_scale(da, p[0] * pk(0));
 #pragma unroll
             for (int j = 0; j < DEN_MAXTOK - 2; ++j)
                 if (j < N) {
@@ -353,12 +376,12 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_bwd(const DenBwdArgs a) {
                     dq = f4_fma(dsj, ld4(a.ctab + ((size_t)b * N + j) * SEEME_CROW + l * 512 + 4 * lane), dq);
                     if (w0) {
                         st4(a.dctab + ((size_t)b * N + j) * SEEME_CROW + l * 512 + 4 * lane, f4_scale(q, dsj));
-                        st4(a.dctab + ((size_t)b * N + j) * SEEME_CROW + l * 512 + 256 + 4 * lane, f4_scale(da, p[1 + j]));
+                        st4(a.dctab + ((size_t)b * N + j) * SEEME_CROW + l * 512 + 256 + 4 * lane, f4_scale(da, p[1 + j] * pk(1 + j)));
                     }
                 }
             const float dst = pt * (dpt - dsum) * scale;
             dq = f4_fma(dst, ld4(tt + l * 512 + 4 * lane), dq);
-            if (w0) { st4(dtt + l * 512 + 4 * lane, f4_scale(q, dst)); st4(dtt + l * 512 + 256 + 4 * lane, f4_scale(da, pt)); }
+            if (w0) { st4(dtt + l * 512 + 4 * lane, f4_scale(q, dst)); st4(dtt + l * 512 + 256 + 4 * lane, f4_scale(da, pt * pk(1 + N))); }
             if (gw) {
                 st4(gw + DB_X_INP + 4 * lane, ld4(sv + DT_X + 4 * lane));
                 st4(gw + DB_Y_INP + 4 * lane, dq); st4(gw + DB_Y_INP + 256 + 4 * lane, dk0); st4(gw + DB_Y_INP + 512 + 4 * lane, dv0);
@@ -390,9 +413,17 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_bwd(const DenBwdArgs a) {
     if (w0) st4(go0 + DB_DX0 + 4 * lane, dx);
 }
 
+static_assert(DM_TOTAL == SEEME_DEN_DROP_BYTES, "dropout mask block: header constant out of date");
 extern "C" int seeme_denoiser_backward(const SeemeDenoiserWeights* w, const void* img_bwd, int B, int N, const float* save,
                                        const float* ctab, const float* ttab, const int32_t* trow, const float* dout,
                                        float* gout, float* dctab, float* dttab, void* stream) {
+    return seeme_denoiser_backward_drop(w, img_bwd, B, N, save, ctab, ttab, trow, dout, gout, dctab, dttab, nullptr, 1.f, stream);
+}
+
+extern "C" int seeme_denoiser_backward_drop(const SeemeDenoiserWeights* w, const void* img_bwd, int B, int N, const float* save,
+                                            const float* ctab, const float* ttab, const int32_t* trow, const float* dout,
+                                            float* gout, float* dctab, float* dttab, const unsigned char* drop, float drop_scale,
+                                            void* stream) {
     if (B <= 0) return seeme_fail("denoiser_backward: B must be > 0");
     if (N < 1 || N > DEN_MAXTOK - 2) return seeme_fail("denoiser_backward: 1 <= N <= 4 condition tokens");
     if (w->nhead != 1 || w->sa_fold || w->wdtype != 0) return seeme_fail("denoiser_backward: one head, unfolded fp32 image");
@@ -401,6 +432,7 @@ extern "C" int seeme_denoiser_backward(const SeemeDenoiserWeights* w, const void
     a.wb = img_bwd; a.lb = seeme_make_den_layout_bwd(); a.wb_bytes = (int)(a.lb.total * 4);
     a.vp = w->vp; a.lay = seeme_make_den_layout(FF_SA, FF_D);
     a.B = B; a.N = N; a.save = save; a.ctab = ctab; a.ttab = ttab; a.trow = trow; a.dout = dout;
+    a.drop = drop; a.drop_scale = drop_scale;
     a.gout = gout; a.dctab = dctab; a.dttab = dttab;
     hipLaunchKernelGGL(k_den_bwd, dim3(B), dim3(DEN_THREADS), 0, (hipStream_t)stream, a);
     return seeme_check_launch("k_den_bwd");

@@ -248,6 +248,21 @@ class TrainPack:
                                              self._vdst, self._nvec, self.vp.data_ptr(), L.current_stream()), "seeme_den_train_pack")
 
 
+DROP_BYTES = 10960          # SEEME_DEN_DROP_BYTES: 5 layers x 2192 mask bytes per sample (csrc/den_train.h DM_*)
+
+
+def draw_dropout_masks(den, B: int, out: torch.Tensor = None):
+    """Keep-masks of the MD layers' dropout sites for one training forward (uint8 [B, DROP_BYTES], 1 = keep), or None in eval mode
+    / with p = 0.  The reference applies nn.Dropout(p) at these sites whenever the module is in training mode
+    (mdiff_transformer.py:137-165,241-254; cross_attention.py:264-273).  Returns (masks, 1 / (1 - p))."""
+    p = float(den.encoder.blocks()[0].sa_block.self_attn.dropout)
+    if not den.training or p <= 0.0:
+        return None, 1.0
+    m = out if out is not None else torch.empty(B, DROP_BYTES, dtype=torch.uint8, device=den.query_pos.pe.device)
+    m.bernoulli_(1.0 - p)
+    return m, 1.0 / (1.0 - p)
+
+
 def _tables(den, cond_sf: torch.Tensor, emb: torch.Tensor):
     """Differentiable table builders: ctab [B,N,5120], ttab [B,7680] in the layouts of include/seeme_hip.h."""
     blocks = den.encoder.blocks()
@@ -290,8 +305,11 @@ class _Chain(torch.autograd.Function):
         a.latents, a.ctab, a.ttab, a.trow, a.trow_per_sample = lat.data_ptr(), ctab.data_ptr(), ttab.data_ptr(), trow.data_ptr(), 1
         a.coef, a.noise, a.out, a.catab = 0, 0, out.data_ptr(), 0
         a.save, a.force_query = save.data_ptr(), 1
+        masks, scale = draw_dropout_masks(pack.den, B)
+        a.drop, a.drop_scale = L.ptr(masks), scale
         L.check(L.lib().seeme_denoiser_sample(C.byref(pack.w), C.byref(a), L.current_stream()), "seeme_denoiser_sample")
-        ctx.pack, ctx.N = pack, N
+        ctx.pack, ctx.N, ctx.masks, ctx.drop_scale = pack, N, masks, scale
+        pack.last_masks = masks
         ctx.save_for_backward(save, ctab, ttab, trow)
         return out
 
@@ -303,9 +321,10 @@ class _Chain(torch.autograd.Function):
         lay = pack.lay
         gout = torch.zeros(B, lay["DB_TOTAL"], device=dev, dtype=torch.float32)
         dctab, dttab = torch.empty_like(ctab), torch.empty_like(ttab)
-        L.check(L.lib().seeme_denoiser_backward(C.byref(pack.w), pack.img_b.data_ptr(), B, N, save.data_ptr(), ctab.data_ptr(),
-                                                 ttab.data_ptr(), trow.data_ptr(), dout.contiguous().data_ptr(), gout.data_ptr(),
-                                                 dctab.data_ptr(), dttab.data_ptr(), L.current_stream()), "seeme_denoiser_backward")
+        L.check(L.lib().seeme_denoiser_backward_drop(C.byref(pack.w), pack.img_b.data_ptr(), B, N, save.data_ptr(), ctab.data_ptr(),
+                                                      ttab.data_ptr(), trow.data_ptr(), dout.contiguous().data_ptr(), gout.data_ptr(),
+                                                      dctab.data_ptr(), dttab.data_ptr(), L.ptr(ctx.masks), ctx.drop_scale,
+                                                      L.current_stream()), "seeme_denoiser_backward")
         # the chain's own parameters do not travel through autograd: their gradients are reduced straight into .grad
         pack.reduce_into_grads(gout)
         fin = 5 * lay["DB_LAYER"]

@@ -23,7 +23,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib as L
-from .denoiser_train import TrainPack, hip_train_supported
+from .denoiser_train import DROP_BYTES, TrainPack, draw_dropout_masks, hip_train_supported
 
 
 def _tiles(M, N):
@@ -108,6 +108,8 @@ class _Plan:
         self.dcond, self.demb, self.dpre1 = z(M, 256), z(B, 256), z(B, 256)
         self.busy = False
         self._bwd_key = None
+        self.drop = torch.zeros(B, DROP_BYTES, dtype=torch.uint8, device=dev)      # dropout keep-masks of the chain (training mode)
+        self.masks, self.drop_scale = None, 1.0
         blocks = den.encoder.blocks()
         te = den.time_embedding
         P = lambda t: t.data_ptr()
@@ -300,6 +302,8 @@ class Stage2Glue:
         s.latents, s.ctab, s.ttab, s.trow, s.trow_per_sample = plan.noisy.data_ptr(), plan.ctab.data_ptr(), plan.ttab.data_ptr(), plan.trow.data_ptr(), 1
         s.coef, s.noise, s.out, s.catab = 0, 0, plan.out.data_ptr(), 0
         s.save, s.force_query = plan.save.data_ptr(), 1
+        plan.masks, plan.drop_scale = draw_dropout_masks(self.den, B, out=plan.drop)
+        s.drop, s.drop_scale = L.ptr(plan.masks), plan.drop_scale
         L.check(L.lib().seeme_denoiser_sample(C.byref(pack.w), C.byref(s), st), "seeme_denoiser_sample")
         plan.busy = True
         plan._keep = (dist, eps_z, eps_c, noise, timesteps)
@@ -309,9 +313,10 @@ class Stage2Glue:
         pack, st = self.pack, L.current_stream()
         B, N = plan.B, plan.N
         plan.gout.zero_()
-        L.check(L.lib().seeme_denoiser_backward(C.byref(pack.w), pack.img_b.data_ptr(), B, N, plan.save.data_ptr(), plan.ctab.data_ptr(),
-                                                 plan.ttab.data_ptr(), plan.trow.data_ptr(), dout.contiguous().data_ptr(),
-                                                 plan.gout.data_ptr(), plan.dctab.data_ptr(), plan.dttab.data_ptr(), st), "seeme_denoiser_backward")
+        L.check(L.lib().seeme_denoiser_backward_drop(C.byref(pack.w), pack.img_b.data_ptr(), B, N, plan.save.data_ptr(), plan.ctab.data_ptr(),
+                                                      plan.ttab.data_ptr(), plan.trow.data_ptr(), dout.contiguous().data_ptr(),
+                                                      plan.gout.data_ptr(), plan.dctab.data_ptr(), plan.dttab.data_ptr(),
+                                                      L.ptr(plan.masks), plan.drop_scale, st), "seeme_denoiser_backward")
         pack.reduce_into_grads(plan.gout)            # chain weights (overwrites its block of the bucket) -- BEFORE the accumulations below
         plan.bind_grads(self)
         plan.g_b0.launch()

@@ -413,7 +413,7 @@ def test_stage2_glue_matches_autograd_path(dev, cfg_name, B):
             rs = model.train_diffusion_forward(tb, noise=noise, timesteps=ts, eps=eps, masks=masks)
             loss = model.losses["train"].update(rs)
             loss.backward()
-            out.append((float(loss), rs["noise_pred"].detach().clone(),
+            out.append((float(loss.detach()), rs["noise_pred"].detach().clone(),
                         {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}))
         assert (getattr(model, "_glue", None) is not None) == glue
         got.append(out)

@@ -456,6 +456,7 @@ def test_training_step_scene_interactee(dev):
     ts = torch.randint(0, 1000, (4,), generator=g).to(dev)
     losses = []
     for _ in range(8):
+        torch.manual_seed(5)                                 # the same rsample noise and dropout masks every step: a fixed objective
         rs = model.train_diffusion_forward(batch, noise=noise, timesteps=ts)
         # frozen stochastic parts (vae rsample) make z differ per call: fix by reusing the first target
         loss = model.losses["train"].update(rs)
@@ -793,10 +794,20 @@ def test_hip_backward_matches_autograd(dev, N):
         out = fn(den, sample, t, cond)
         loss = torch.nn.functional.mse_loss(out, target)
         loss.backward()
-        return out.detach(), float(loss), {k: (p.grad.clone() if p.grad is not None else None) for k, p in den.named_parameters()}, cond.grad.clone()
+        return out.detach(), float(loss.detach()), {k: (p.grad.clone() if p.grad is not None else None) for k, p in den.named_parameters()}, cond.grad.clone()
 
-    o_ref, l_ref, g_ref, c_ref = run(denoiser_forward_torch)
+    # training mode: the HIP path draws the keep-masks of the MD layers' dropout sites (mdiff_transformer.py:137-165,241-254;
+    # cross_attention.py:264-273); the twin gets those very masks, so the comparison covers dropout forward and backward
     o_hip, l_hip, g_hip, c_hip = run(denoiser_forward_hip_train)
+    masks = den._train_pack.last_masks
+    assert masks is not None and masks.shape == (B, 10960) and abs(float(masks.float().mean()) - 0.9) < 0.02
+    o_ref, l_ref, g_ref, c_ref = run(lambda d, s_, t_, c_: denoiser_forward_torch(d, s_, t_, c_, masks=masks.clone()))
+    den.eval()                                               # eval mode: no masks are drawn, the arithmetic is the inference one
+    o_ev = denoiser_forward_hip_train(den, sample, t, cond)
+    assert den._train_pack.last_masks is None
+    assert rel_err(o_ev.detach().cpu().numpy(), denoiser_forward_torch(den, sample, t, cond).detach().cpu().numpy()) < TOL_F32
+    assert rel_err(o_ev.detach().cpu().numpy(), o_hip.cpu().numpy()) > 1e-2     # ... and dropout did change the training forward
+    den.train()
     assert rel_err(o_hip.cpu().numpy(), o_ref.cpu().numpy()) < TOL_F32 and abs(l_hip - l_ref) < 1e-5 * max(1.0, abs(l_ref))
     assert rel_err(c_hip.cpu().numpy(), c_ref.cpu().numpy()) < 2e-4
     worst = ("", 0.0)
@@ -818,14 +829,17 @@ def test_hip_backward_matches_autograd(dev, N):
             worst = (k, e)
     print(f"HIP backward vs autograd (N={N}): worst parameter-gradient rel err {worst[1]:.3e} at {worst[0]}")
     assert worst[1] < 5e-4, worst
-    # gradient accumulation: a second backward without zero_grad adds to the first (the .grad views are still in use)
+    # gradient accumulation: a second backward without zero_grad adds to the first (the .grad views are still in use);
+    # in eval mode, so that both passes are the same function
+    den.eval()
+    _, _, g_one, _ = run(denoiser_forward_hip_train)
     out = denoiser_forward_hip_train(den, sample, t, cond)
     torch.nn.functional.mse_loss(out, target).backward()
     k = "encoder.middle_block.sa_block.linear1.weight"
     acc = dict(den.named_parameters())[k].grad
-    assert rel_err(acc.cpu().numpy(), 2 * g_hip[k].cpu().numpy()) < 1e-5
+    assert rel_err(acc.cpu().numpy(), 2 * g_one[k].cpu().numpy()) < 1e-5
     kin = "encoder.middle_block.sa_block.self_attn.in_proj_weight"          # shared by the chain and the tables
-    assert rel_err(dict(den.named_parameters())[kin].grad.cpu().numpy(), 2 * g_hip[kin].cpu().numpy()) < 1e-5
+    assert rel_err(dict(den.named_parameters())[kin].grad.cpu().numpy(), 2 * g_one[kin].cpu().numpy()) < 1e-5
 
 
 def test_vae_autograd_twin_matches_hip_and_stage1_trains(dev):
