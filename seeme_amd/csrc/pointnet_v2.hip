@@ -53,18 +53,23 @@ typedef __bf16 p2_bf16x2 __attribute__((ext_vector_type(2)));
 #define P2_SLOT_U4 1024           // uint4 per slot
 #define P2_RING 3                 // ring positions: slot s is read during step s (its first fragments already before the barrier that
                                   // opens the step), slot s + 2 is written during step s, slot s + 3 is in flight from L2
-#define P2_RING_BYTES (P2_RING * 16384)
+#ifndef P2_SPB
+#define P2_SPB 1                  // steps per barrier: the ring turns (barrier, ds_write of the staged weights, next requests) every
+#endif                            // P2_SPB steps, on ring positions of P2_SPB x 16 KiB
+#define P2_NQ (P2_SLOTS / P2_SPB) // ring turns per tile
+#define P2_RING_BYTES (P2_RING * P2_SPB * 16384)
 #ifndef P2_PRE
 #define P2_PRE 4                  // weight fragments read ahead of the MFMAs that consume them
 #endif
 static_assert(16 % P2_PRE == 0, "the fragment ring carries over from slot to slot: 16 fragments per slot must be a multiple of its depth");
 #ifndef P2_WLA
-#define P2_WLA 2                  // steps a weight slot spends in staging registers between its load and its ds_write (L2 latency)
+#define P2_WLA (P2_SPB == 1 ? 2 : 1)  // ring turns a weight slot spends in staging registers between its load and its ds_write (L2 latency)
 #endif
 #ifndef P2_XLA
 #define P2_XLA 2                  // steps between the load of an input k-block and its use (first touch comes from HBM)
 #endif
-static_assert(P2_SLOTS % P2_WLA == 0 && P2_SLOTS % (P2_XLA + 1) == 0, "ring positions are compile-time constants across tiles");
+static_assert(P2_SLOTS % P2_SPB == 0 && P2_NQ % P2_WLA == 0 && P2_NQ % P2_RING == 0 && P2_SLOTS % (P2_XLA + 1) == 0,
+              "ring positions are compile-time constants across tiles");
 #ifndef P2_PRIO
 #define P2_PRIO 1                 // s_setprio of waves 4..7
 #endif
@@ -140,15 +145,15 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
 
     // ---- the weight stream: slot q of the tile program = stream[q % 24]; this wave moves 2 KiB of each slot
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.stream), 0, P2_SLOTS * 16384, 0x00020000);
-    constexpr int WP = 16 / P2_NW;                                        // KiB pieces of a slot per wave
+    constexpr int WP = 16 * P2_SPB / P2_NW;                               // KiB pieces of a ring position per wave
     const unsigned w_lane = (unsigned)(wave * WP * 1024 + lane * 16);     // byte offset of this lane's 16 B inside a slot (first piece)
     p2_u32x4 stg[P2_WLA][WP];               // slot q waits in set q % P2_WLA: stored into the ring at the top of step q - 2, re-filled right after
     auto w_load = [&](int slot_in_tile, p2_u32x4 (&dst)[WP]) {
 #pragma unroll
-        for (int i = 0; i < WP; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane + (unsigned)(i * 1024), (unsigned)(slot_in_tile * 16384), 0);
+        for (int i = 0; i < WP; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane + (unsigned)(i * 1024), (unsigned)(slot_in_tile * (P2_SPB * 16384)), 0);
     };
     auto w_store = [&](int ring_pos, const p2_u32x4 (&src)[WP]) {
-        uint4* d = ring + ring_pos * P2_SLOT_U4 + wave * (WP * 64) + lane;
+        uint4* d = ring + ring_pos * (P2_SPB * P2_SLOT_U4) + wave * (WP * 64) + lane;
 #pragma unroll
         for (int i = 0; i < WP; ++i) d[i * 64] = make_uint4(src[i].x, src[i].y, src[i].z, src[i].w);
     };
@@ -256,17 +261,21 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
             // = feature k-block 4 g + j / 2 of point tile j % 2 -- issued behind this step's barrier and requests, below)
             // ---- ring turn: slot s was written one step ago; after the barrier it is readable and the other position is free
             P2_STAMP(0);
+            const int q = s / P2_SPB, h = s % P2_SPB;               // ring turn of the tile, step inside the turn
+            if (h == 0) {
 #ifndef P2_ABL_NOBAR
-            __syncthreads();
+                __syncthreads();
 #endif
-            P2_STAMP(1);
 #ifndef P2_ABL_NORING
-            if (s + 2 < P2_SLOTS || more) w_store((s + 2) % P2_RING, stg[(s + 2) % P2_WLA]);
-            if (s + 2 + P2_WLA < P2_SLOTS) w_load(s + 2 + P2_WLA, stg[(s + 2) % P2_WLA]);
-            else if (more) w_load(s + 2 + P2_WLA - P2_SLOTS, stg[(s + 2) % P2_WLA]);
+                if (q + 2 < P2_NQ || more) w_store((q + 2) % P2_RING, stg[(q + 2) % P2_WLA]);
+                if (q + 2 + P2_WLA < P2_NQ) w_load(q + 2 + P2_WLA, stg[(q + 2) % P2_WLA]);
+                else if (more) w_load(q + 2 + P2_WLA - P2_NQ, stg[(q + 2) % P2_WLA]);
 #endif
-            const uint4* const rp = rl + (s % P2_RING) * P2_SLOT_U4;
-            const uint4* const rn = rl + ((s + 1) % P2_RING) * P2_SLOT_U4;     // the next slot: complete since the barrier above
+            }
+            P2_STAMP(1);
+            const uint4* const rp = rl + ((q % P2_RING) * P2_SPB + h) * P2_SLOT_U4;
+            // the next step's fragments: inside this ring position, or the next position (complete since the barrier above)
+            const uint4* const rn = rl + (h + 1 < P2_SPB ? (q % P2_RING) * P2_SPB + h + 1 : ((q + 1) % P2_RING) * P2_SPB) * P2_SLOT_U4;
             if (!FIRST) {                                      // x k-block of step s + 2 (k-block = step % 8), across the tile boundary
 #ifndef P2_ABL_NOX
                 if (s + P2_XLA == P2_SLOTS && more) rx = tile_rsrc(t + 1);
