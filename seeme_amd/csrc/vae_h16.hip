@@ -751,6 +751,9 @@ static int launch_ffn_h(const FfnHArgs& a, hipStream_t st) {
 // LDS: R0 = [32][Sp+8] fp32 (scores -> out_proj tile -> hidden operand -> FFN output tile -> tail tiles), R1 = [32][272]
 // fp16 (Q -> O -> x operand -> hidden -> x operand): 51 KB at Sp = 256, three workgroups per CU.  LN1's output rows stay in
 // registers (8 float4 per lane) as the FFN residual.
+#ifndef LAYER_WPE
+#define LAYER_WPE 2      // workgroups per CU the register allocation aims at (3 would need <= 168 VGPRs)
+#endif
 struct LayerHArgs {
     const unsigned short* qk; const unsigned short* vt; const float* res;
     const uint4* wo; const float* bo; const float* n1_w; const float* n1_b;
@@ -806,7 +809,7 @@ __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned
     }
 }
 
-__global__ __launch_bounds__(256) void k_layer_h(const LayerHArgs a) {
+__global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
     const int ldp = a.Sp + LDS_PAD, ldq = 256 + HPAD, ldph = 2 * ldp, ldc = 256 + LDS_PAD;
