@@ -412,6 +412,11 @@ typedef struct {
 } SeemeGemmProblem;              /* accumulate: 0 store, 1 C += (one writer), 2 atomicAdd (nbatch members share C: split reduction) */
 int seeme_grouped_gemm(const SeemeGemmProblem* probs_dev, int n_probs, int n_tiles, void* stream);
 int seeme_gemm_problem_bytes(void);
+/* Plain large fp32 GEMM on the matrix cores (the projections of the stage-1 training step): C[M,N] = A[M,K] B + bias[N] + addend,
+ * B = W[N,K] (b_is_nt: y = x W^T, F.linear) or W[K,N] (data gradient dx = dy W).  M, N multiples of 128, K of 32, operands 16-byte
+ * aligned with strides in multiples of 4 floats; anything else goes through seeme_grouped_gemm. */
+int seeme_gemm128(const float* A, long lda, const float* B, long ldb, int b_is_nt, float* C, long ldc, int M, int N, int K,
+                  const float* bias, const float* addend, long add_ld, void* stream);
 
 /* Element-wise middle of the backward: d cond = sum_l dcs[l] + LayerNorm-backward(sum_l dxl[l] * tn_w[l]); text_norm
  * affine gradients g_tn_w[l] += sum_m dxl[l]*xhat, g_tn_b[l] += sum_m dxl[l]; d emb = sum_5 dea + SiLU'(emb) * sum_10 deb. */

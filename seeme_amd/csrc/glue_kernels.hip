@@ -273,18 +273,50 @@ __global__ __launch_bounds__(256) void k_gg(const SeemeGemmProblem* __restrict__
         }
         __syncthreads();
     }
+    {   // epilogue: every optional operand behind a UNIFORM branch around straight-line code (loads clamped to a valid address and
+        // batched), not behind per-element branches, which serialise 16 round trips per lane
+        const int j = j0 + 32 * wj + (ln & 31), jc = j < N ? j : N - 1;
+        const long ib = i0 + 32 * wi + 4 * (ln >> 5);
+        auto row = [&](int v) { return ib + 8 * (v >> 2) + (v & 3); };
+        auto rowc = [&](int v) { const long i = row(v); return i < M ? i : (long)M - 1; };
+        float val[16];
+        const float bv = P.bias ? ((const gfloat*)P.bias)[jc] : 0.f;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const int i = i0 + 32 * wi + 8 * (v >> 2) + 4 * (ln >> 5) + (v & 3), j = j0 + 32 * wj + (ln & 31);
-        if (i >= M || j >= N) continue;
-        float val = acc[v];
-        if (P.bias) val += P.bias[j];
-        if (P.epi == 1) val *= dsilu_f(P.e0[(long)i * P.e_ld + j]);
-        else if (P.epi == 2) val *= P.alpha;
-        if (P.addend) val += P.addend[(long)i * P.add_ld + j];
-        float* dst = P.c + c_boff + (long)i * P.ldc + j;
-        if (P.accumulate == 2) atomicAdd(dst, val);          // split reductions (nbatch members sharing one C)
-        else *dst = P.accumulate ? *dst + val : val;
+        for (int v = 0; v < 16; ++v) val[v] = acc[v] + bv;
+        if (P.epi == 1) {
+            const gfloat* e0 = (const gfloat*)P.e0;
+            float ev[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) ev[v] = e0[rowc(v) * P.e_ld + jc];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) val[v] *= dsilu_f(ev[v]);
+        } else if (P.epi == 2) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) val[v] *= P.alpha;
+        }
+        if (P.addend) {
+            const gfloat* ad = (const gfloat*)P.addend;
+            float av[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) av[v] = ad[rowc(v) * P.add_ld + jc];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) val[v] += av[v];
+        }
+        float* cb = P.c + c_boff;
+        if (P.accumulate == 1) {
+            float cv[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) cv[v] = ((const gfloat*)cb)[rowc(v) * P.ldc + jc];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) val[v] += cv[v];
+        }
+        if (P.accumulate == 2) {                     // split reductions (nbatch members sharing one C)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) if (row(v) < M && j < N) atomicAdd(cb + row(v) * P.ldc + j, val[v]);
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) if (row(v) < M && j < N) cb[row(v) * P.ldc + j] = val[v];
+        }
     }
 #else
     float acc[4][4] = {};
@@ -389,3 +421,125 @@ extern "C" int seeme_grouped_gemm(const SeemeGemmProblem* probs_dev, int n_probs
 }
 
 extern "C" int seeme_gemm_problem_bytes(void) { return (int)sizeof(SeemeGemmProblem); }
+
+// ------------------------------------------------------------------ plain large GEMM (the projections of the stage-1 step)
+// C[M,N] = A[M,K] B + bias + addend for M, N multiples of 128 and K a multiple of 32: 128 x 128 x 32 tiles, wave quadrants of
+// 2 x 2 v_mfma_f32_32x32x2_f32 accumulators, dwordx4 operand loads without guards or prologues, double-buffered LDS with one
+// barrier per k-step (the next step's loads are in flight while this step's 64 MFMAs per wave run).  B is W[N,K] (NT: forward
+// projection y = x W^T) or W[K,N] (NN: data gradient dx = dy W).  What k_gg does for problems of any shape, at 2.5x its rate.
+typedef float g1_f32x4 __attribute__((ext_vector_type(4)));
+typedef g1_f32x4 __attribute__((address_space(1))) g1_gfloat4;
+typedef float g1_f32x16 __attribute__((ext_vector_type(16)));
+
+template <bool NT>
+__global__ __launch_bounds__(256, 2) void k_gemm128(const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb,
+                                                    float* __restrict__ C, long ldc, int K, const float* __restrict__ bias,
+                                                    const float* __restrict__ addend, long add_ld, int tiles_n) {
+    constexpr int LDA = 129, LDB = NT ? 129 : 132;
+    extern __shared__ __attribute__((aligned(16))) float g1_smem[];            // 66 KB: above the static limit
+    float (*As)[32][LDA] = reinterpret_cast<float (*)[32][LDA]>(g1_smem + 2 * 32 * LDB);
+    float (*Bs)[32][LDB] = reinterpret_cast<float (*)[32][LDB]>(g1_smem);
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63, wi = wv >> 1, wj = wv & 1;
+    const int i0 = (blockIdx.x / tiles_n) * 128, j0 = (blockIdx.x % tiles_n) * 128;
+    const gfloat* Ap = (const gfloat*)A + (long)i0 * lda;
+    const gfloat* Bp = (const gfloat*)B + (NT ? (long)j0 * ldb : (long)j0);
+    g1_f32x4 ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            ra[g] = *(const g1_gfloat4*)(Ap + (long)((t >> 3) + 32 * g) * lda + k0 + 4 * (t & 7));
+            if (NT) rb[g] = *(const g1_gfloat4*)(Bp + (long)((t >> 3) + 32 * g) * ldb + k0 + 4 * (t & 7));
+            else rb[g] = *(const g1_gfloat4*)(Bp + (long)(k0 + (t >> 5) + 8 * g) * ldb + 4 * (t & 31));
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = (t >> 3) + 32 * g, kk = 4 * (t & 7);
+            As[buf][kk][row] = ra[g].x; As[buf][kk + 1][row] = ra[g].y; As[buf][kk + 2][row] = ra[g].z; As[buf][kk + 3][row] = ra[g].w;
+            if (NT) { Bs[buf][kk][row] = rb[g].x; Bs[buf][kk + 1][row] = rb[g].y; Bs[buf][kk + 2][row] = rb[g].z; Bs[buf][kk + 3][row] = rb[g].w; }
+            else *reinterpret_cast<g1_f32x4*>(&Bs[buf][(t >> 5) + 8 * g][4 * (t & 31)]) = rb[g];
+        }
+    };
+    g1_f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[x][y][v] = 0.f;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    const int nk = K / 32;
+    for (int s = 0; s < nk; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nk) fetch(32 * (s + 1));
+        const float* ap0 = &As[buf][ln >> 5][64 * wi + (ln & 31)];
+        const float* bp0 = &Bs[buf][ln >> 5][64 * wj + (ln & 31)];
+        float fa[2][4][2], fb[2][4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) { fa[0][q][x] = ap0[2 * q * LDA + 32 * x]; fb[0][q][x] = bp0[2 * q * LDB + 32 * x]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c + 1 < 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) {
+                        fa[(c + 1) & 1][q][x] = ap0[(8 * (c + 1) + 2 * q) * LDA + 32 * x];
+                        fb[(c + 1) & 1][q][x] = bp0[(8 * (c + 1) + 2 * q) * LDB + 32 * x];
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][q][x], fb[c & 1][q][y], acc[x][y], 0, 0, 0);
+        }
+        if (s + 1 < nk) stage(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: uniform branches around straight-line code -- a load under a per-element branch is waited for on the spot, and 64
+    // outputs per lane would be 64 serialised round trips (they were: the epilogue cost more than the 8 k-steps before it)
+    float bj[2] = {0.f, 0.f};
+    if (bias) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y) bj[y] = bias[j0 + 64 * wj + 32 * y + (ln & 31)];
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const long ib = i0 + 64 * wi + 32 * x + 4 * (ln >> 5), j = j0 + 64 * wj + 32 * y + (ln & 31);
+            if (addend) {
+                float ad[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) ad[v] = addend[(ib + 8 * (v >> 2) + (v & 3)) * add_ld + j];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[x][y][v] += ad[v];
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) C[(ib + 8 * (v >> 2) + (v & 3)) * ldc + j] = acc[x][y][v] + bj[y];
+        }
+}
+
+extern "C" int seeme_gemm128(const float* A, long lda, const float* B, long ldb, int b_is_nt, float* C, long ldc, int M, int N, int K,
+                             const float* bias, const float* addend, long add_ld, void* stream) {
+    if (!A || !B || !C || M < 128 || N < 128 || K < 32 || (M & 127) || (N & 127) || (K & 31) || (lda & 3) || (ldb & 3) ||
+        ((size_t)A & 15) || ((size_t)B & 15))
+        return seeme_fail("seeme_gemm128: M, N multiples of 128, K of 32, 16-byte aligned operands with strides in multiples of 4");
+    const int tiles_n = N / 128, tiles = (M / 128) * tiles_n;
+    const size_t lds = (size_t)2 * 32 * (129 + (b_is_nt ? 129 : 132)) * 4;
+    if (b_is_nt) {
+        SEEME_HIP(hipFuncSetAttribute((const void*)k_gemm128<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_gemm128<true>, dim3(tiles), dim3(256), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, K, bias, addend, add_ld, tiles_n);
+    } else {
+        SEEME_HIP(hipFuncSetAttribute((const void*)k_gemm128<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_gemm128<false>, dim3(tiles), dim3(256), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, K, bias, addend, add_ld, tiles_n);
+    }
+    return seeme_check_launch("k_gemm128");
+}

@@ -22,6 +22,7 @@ one head, S > 512) and as the oracle of ``tests/test_gpu_flows.py::test_vae_hip_
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List
 
 import torch
@@ -63,6 +64,18 @@ class _Ops:
     def gemm(self, *probs):
         g = _Group(list(probs), self.dev)
         self.ops.append(g.launch)
+
+    def plain(self, A, lda, B, ldb, nt, Cp, ldc, M, N, K, bias=0, addend=0, add_ld=0):
+        """C[M,N] = A[M,K] B + bias + addend, B = W[N,K] (nt: y = x W^T) or W[K,N] (data gradient): the specialised 128 x 128 kernel
+        when the shape allows (M, N multiples of 128, K of 32), else a problem of the grouped GEMM."""
+        if M % 128 == 0 and N % 128 == 0 and K % 32 == 0 and lda % 4 == 0 and ldb % 4 == 0 and A % 16 == 0 and B % 16 == 0 \
+                and os.environ.get("SEEME_GEMM128", "1") != "0":
+            self.ops.append(lambda: L.check(L.lib().seeme_gemm128(A, lda, B, ldb, 1 if nt else 0, Cp, ldc, M, N, K, bias, addend, add_ld,
+                                                                   L.current_stream()), "seeme_gemm128"))
+        elif nt:
+            self.gemm(_gemm_fwd([A], lda, B, ldb, [K], bias, Cp, ldc, M, N, addend=addend, add_ld=add_ld))
+        else:
+            self.gemm(_gemm_dgrad(A, lda, B, ldb, K, N, Cp, ldc, M, bias=bias, addend=addend, add_ld=add_ld))
 
     def add_ln(self, sub, res, norm, y, xhat, rstd, M, sub_seq_rows=0):
         a = L.VtLn()
@@ -156,7 +169,7 @@ class _StackPlan:
     def _layer_fwd(self, ops: _Ops, l: int, x_in: int):
         lp, sv, B, S, M = self.layers[l], self.sv[l], self.B, self.S, self.M
         sa = lp.self_attn
-        ops.gemm(_gemm_fwd([x_in], 256, P(sa.in_proj_weight), 256, [256], P(sa.in_proj_bias), P(sv["qkv"]), 768, M, 768))
+        ops.plain(x_in, 256, P(sa.in_proj_weight), 256, True, P(sv["qkv"]), 768, M, 768, 256, bias=P(sa.in_proj_bias))
         q = P(sv["qkv"])
         ops.gemm(_prob([q], [q + 4 * 256], [256], [1], [1], 768, 768, P(sv["P"]), S, S, S, nbatch=B, bstrides=(S * 768, S * 768, S * S)))
         n_prefix = 0 if self.dec else 2
@@ -169,7 +182,7 @@ class _StackPlan:
             pv = P(sv["Pd"])
         ops.gemm(_prob([pv], [q + 4 * 512], [S], [1], [768], S, 1, P(sv["O"]), 256, S, 256, nbatch=B,
                        bstrides=(S * S, S * 768, S * 256)))
-        ops.gemm(_gemm_fwd([P(sv["O"])], 256, P(sa.out_proj.weight), 256, [256], P(sa.out_proj.bias), P(self.tmp), 256, M, 256))
+        ops.plain(P(sv["O"]), 256, P(sa.out_proj.weight), 256, True, P(self.tmp), 256, M, 256, 256, bias=P(sa.out_proj.bias))
         if dr:
             ops.dropout(P(self.tmp), P(sv["m1"]), ds, P(self.tmp), M * 256)           # dropout1
         ops.add_ln(P(self.tmp), x_in, lp.norm1, P(sv["x1"]), P(sv["xh1"]), P(sv["rs1"]), M)
@@ -189,11 +202,11 @@ class _StackPlan:
                 ops.add_ln(P(sv["cv"]), x1, lp.norm2, P(sv["x1b"]), P(sv["xh1b"]), P(sv["rs1b"]), M, sub_seq_rows=S)
             x1 = P(sv["x1b"])
             n_ffn = lp.norm3
-        ops.gemm(_gemm_fwd([x1], 256, P(lp.linear1.weight), 256, [256], P(lp.linear1.bias), P(sv["hpre"]), 128, M, 128))
+        ops.plain(x1, 256, P(lp.linear1.weight), 256, True, P(sv["hpre"]), 128, M, 128, 256, bias=P(lp.linear1.bias))
         ops.call(lambda a=P(sv["hpre"]), o=P(sv["h"]): L.check(L.lib().seeme_vt_gelu(a, 0, o, M * 128, L.current_stream()), "seeme_vt_gelu"))
         if dr:
             ops.dropout(P(sv["h"]), P(sv["mh"]), ds, P(sv["h"]), M * 128)               # dropout inside the FFN
-        ops.gemm(_gemm_fwd([P(sv["h"])], 128, P(lp.linear2.weight), 128, [128], P(lp.linear2.bias), P(self.tmp), 256, M, 256))
+        ops.plain(P(sv["h"]), 128, P(lp.linear2.weight), 128, True, P(self.tmp), 256, M, 256, 128, bias=P(lp.linear2.bias))
         if dr:
             ops.dropout(P(self.tmp), P(sv["m2"]), ds, P(self.tmp), M * 256)           # dropout2 (decoder: dropout3)
         ops.add_ln(P(self.tmp), x1, n_ffn, P(sv["x2"]), P(sv["xh2"]), P(sv["rs2"]), M)
@@ -245,12 +258,12 @@ class _StackPlan:
         if dr:
             ops.dropout(P(self.G2), P(sv["m2"]), ds, P(self.Gm), M * 256)
             g2 = P(self.Gm)
-        ops.gemm(_gemm_dgrad(g2, 256, P(lp.linear2.weight), 128, 256, 128, P(self.dh), 128, M),
-                 _gemm_wgrad(g2, 256, P(sv["h"]), 128, S, B, G(lp.linear2.weight), 128, 256, 128, G(lp.linear2.bias)))
+        ops.plain(g2, 256, P(lp.linear2.weight), 128, False, P(self.dh), 128, M, 128, 256)
+        ops.gemm(_gemm_wgrad(g2, 256, P(sv["h"]), 128, S, B, G(lp.linear2.weight), 128, 256, 128, G(lp.linear2.bias)))
         if dr:
             ops.dropout(P(self.dh), P(sv["mh"]), ds, P(self.dh), M * 128)
         ops.call(lambda: L.check(L.lib().seeme_vt_gelu(P(sv["hpre"]), P(self.dh), P(self.dhpre), M * 128, L.current_stream()), "seeme_vt_gelu"))
-        ops.gemm(_gemm_dgrad(P(self.dhpre), 128, P(lp.linear1.weight), 256, 128, 256, P(self.DX1), 256, M, addend=P(self.G2), add_ld=256))
+        ops.plain(P(self.dhpre), 128, P(lp.linear1.weight), 256, False, P(self.DX1), 256, M, 256, 128, addend=P(self.G2), add_ld=256)
         wg = [_gemm_wgrad(P(self.dhpre), 128, x1, 256, S, B, G(lp.linear1.weight), 256, 128, 256, G(lp.linear1.bias))]
         d_x1 = P(self.DX1)
         if self.dec:
@@ -277,8 +290,8 @@ class _StackPlan:
         if dr:
             ops.dropout(P(self.G1), P(sv["m1"]), ds, P(self.Gm), M * 256)
             g1 = P(self.Gm)
-        ops.gemm(_gemm_dgrad(g1, 256, P(sa.out_proj.weight), 256, 256, 256, P(self.dO), 256, M),
-                 _gemm_wgrad(g1, 256, P(sv["O"]), 256, S, B, G(sa.out_proj.weight), 256, 256, 256, G(sa.out_proj.bias)))
+        ops.plain(g1, 256, P(sa.out_proj.weight), 256, False, P(self.dO), 256, M, 256, 256)
+        ops.gemm(_gemm_wgrad(g1, 256, P(sv["O"]), 256, S, B, G(sa.out_proj.weight), 256, 256, 256, G(sa.out_proj.bias)))
         q, dq = P(sv["qkv"]), P(self.dqkv)
         pv = P(sv["Pd"]) if dr else P(sv["P"])
         ops.gemm(_prob([P(self.dO)], [q + 4 * 512], [256], [1], [1], 256, 768, P(self.dP), S, S, S, nbatch=B, bstrides=(S * 256, S * 768, S * S)),
@@ -289,7 +302,7 @@ class _StackPlan:
                                  "seeme_vt_softmax_bwd"))
         ops.gemm(_prob([P(self.dP)], [q + 4 * 256], [S], [1], [768], S, 1, dq, 768, S, 256, nbatch=B, bstrides=(S * S, S * 768, S * 768)),
                  _prob([P(self.dP)], [q], [S], [S], [768], 1, 1, dq + 4 * 256, 768, S, 256, nbatch=B, bstrides=(S * S, S * 768, S * 768)))
-        ops.gemm(_gemm_dgrad(dq, 768, P(sa.in_proj_weight), 256, 768, 256, out, 256, M, addend=P(self.G1), add_ld=256))
+        ops.plain(dq, 768, P(sa.in_proj_weight), 256, False, out, 256, M, 256, 768, addend=P(self.G1), add_ld=256)
         wg += [_gemm_wgrad(dq, 768, x_in, 256, S, B, G(sa.in_proj_weight), 256, 768, 256, G(sa.in_proj_bias))]
         ops.gemm(*wg)
 

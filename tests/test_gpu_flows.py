@@ -429,12 +429,14 @@ def test_stage2_glue_matches_autograd_path(dev, cfg_name, B):
         assert errs[0][0] < 5e-5, (it, errs[:6])
 
 
-@pytest.mark.parametrize("cfg_name,B,T", [("config_vae_egobody.yaml", 3, 16), ("config_vae_gimo.yaml", 5, 70)])
+@pytest.mark.parametrize("cfg_name,B,T", [("config_vae_egobody.yaml", 3, 16), ("config_vae_gimo.yaml", 5, 70),
+                                          ("config_vae_egobody.yaml", 64, 14)])
 def test_vae_hip_backward_matches_autograd(dev, cfg_name, B, T):
     """Stage 1 through vae_train.py (hand-written HIP forward with saves + backward of the VAE encoder / decoder: grouped fp32
     GEMMs, LayerNorm / softmax / GELU backward kernels, weight gradients as split atomic reductions) against the same step on
     the PyTorch-autograd twin (TRAIN.HIP_VAE_BACKWARD false; pinned to the HIP forward and the oracle above): loss terms,
-    m_rst, and EVERY parameter gradient, with ragged lengths; T = 70 crosses a 64-row tile edge."""
+    m_rst, and EVERY parameter gradient, with ragged lengths; T = 70 crosses a 64-row tile edge; B = 64 makes the row counts
+    multiples of 128, so the projections run on the specialised seeme_gemm128 kernel (both forms)."""
     got = []
     for hip in (True, False):
         def mut(cfg):
