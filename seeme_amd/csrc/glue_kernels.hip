@@ -431,6 +431,9 @@ typedef float g1_f32x4 __attribute__((ext_vector_type(4)));
 typedef g1_f32x4 __attribute__((address_space(1))) g1_gfloat4;
 typedef float g1_f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef G1_PIN
+#define G1_PIN 1
+#endif
 template <bool NT>
 __global__ __launch_bounds__(256, 2) void k_gemm128(const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb,
                                                     float* __restrict__ C, long ldc, int K, const float* __restrict__ bias,
@@ -499,6 +502,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const float* __restrict__ A,
                 for (int x = 0; x < 2; ++x)
 #pragma unroll
                     for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][q][x], fb[c & 1][q][y], acc[x][y], 0, 0, 0);
+#if G1_PIN
+            // pin the interleave: one fragment read of the NEXT chunk behind each MFMA of this one (left alone the scheduler reads a
+            // k-pair's fragments, waits lgkmcnt(0), multiplies, and the LDS latency is exposed 16 times per k-step)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#endif
         }
         if (s + 1 < nk) stage(buf ^ 1);
         __syncthreads();
