@@ -409,6 +409,7 @@ class VaeTrainer:
     def __init__(self, vae):
         self.vae = vae
         self.plans = {}
+        self._len_cache = {}
         self._T = 0
         self._key = tuple(p.data_ptr() for p in vae.parameters())
 
@@ -436,7 +437,15 @@ class VaeTrainer:
         return p
 
     def _lengths(self, lengths, dev):
-        return torch.as_tensor(lengths, dtype=torch.int32, device=dev)
+        # (cached per value: the list -> device tensor conversion is a synchronous host-to-device copy, twice per step otherwise)
+        key = (tuple(int(v) for v in lengths), str(dev))
+        t = self._len_cache.get(key)
+        if t is None:
+            if len(self._len_cache) > 64:
+                self._len_cache.clear()
+            t = torch.as_tensor(key[0], dtype=torch.int32, device=dev)
+            self._len_cache[key] = t
+        return t
 
     def encode(self, features: torch.Tensor, lengths: List[int]):
         """features [B,T,F] -> (mu [1,B,256], logvar [1,B,256])."""
