@@ -9,7 +9,8 @@ frozen encoders and the loss -- posterior rsample, ``scheduler.add_noise``, time
     backward: k_den_bwd -> seeme_den_wgrad (chain weights) -> k_gg (data gradients of the tables) -> k_glue_mid
               -> k_gg (time MLP) -> k_gg (every weight / bias gradient of the tables, time MLP and output_scene)
 
-with every parameter gradient accumulated straight into ``.grad`` (the views of ``distributed.GradBucket`` once it exists):
+with every parameter gradient accumulated straight into ``.grad`` (the views of ``distributed.GradBucket`` once it exists; the
+weight-gradient descriptor table is rebuilt when those tensors move, so keep them -- ``MLD.optimizer_step`` does):
 autograd sees ONE node (:class:`_Stage2`) instead of ~70 and launches ~12 kernels instead of ~170.  The torch-autograd
 table builders (``denoiser_train._tables``) stay as the fallback for shapes this path does not take, and are the oracle
 of ``tests/test_gpu_flows.py::test_stage2_glue_matches_autograd_path``.

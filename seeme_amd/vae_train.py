@@ -13,7 +13,10 @@ them.  Inside a node everything is launches of ``libseeme_hip.so``:
   softmax over the keys), ``seeme_vt_gelu`` (exact GELU and its derivative), ``seeme_vt_seq_sum`` (the cross-attention
   vector of the single latent token is one row per sequence).
 
-Parameter gradients are accumulated straight into ``.grad`` (the views of ``distributed.GradBucket`` once it exists).
+Parameter gradients are accumulated straight into ``.grad`` (the views of ``distributed.GradBucket`` once it exists).  The
+backward's launch lists hold the addresses of those ``.grad`` tensors: ``MLD.optimizer_step`` keeps them stable (the bucket's
+views); a loop that drops them every step (``zero_grad(set_to_none=True)``) stays correct but re-records ~130 descriptor tables
+per step -- zero them in place instead.
 In training mode the reference's dropout sites are applied (attention weights of ``nn.MultiheadAttention``, ``dropout1/2/3``, the
 FFN's inner dropout; cross_attention.py:264-273,324-337) with keep-masks drawn by one ``bernoulli_`` per stack and step; in eval
 mode the arithmetic is that of the HIP inference path.  The autograd twin (``vae_autograd.py``) stays as the fallback (more than
