@@ -415,6 +415,10 @@ int seeme_gemm_problem_bytes(void);
 /* Plain large fp32 GEMM on the matrix cores (the projections of the stage-1 training step): C[M,N] = A[M,K] B + bias[N] + addend,
  * B = W[N,K] (b_is_nt: y = x W^T, F.linear) or W[K,N] (data gradient dx = dy W).  M, N multiples of 128, K of 32, operands 16-byte
  * aligned with strides in multiples of 4 floats; anything else goes through seeme_grouped_gemm. */
+/* Large weight gradient: G[Nout,Kin] += dY[M,Nout]^T X[M,Kin], gbias[Nout] += column sums of dY (NULL to skip); Nout, Kin
+ * multiples of 128; split over row chunks with atomic accumulation (G must hold the value to add to). */
+int seeme_wgrad128(const float* dY, long ldy, const float* X, long ldx, int M, int Nout, int Kin, float* G, long ldg, float* gbias,
+                   void* stream);
 int seeme_gemm128(const float* A, long lda, const float* B, long ldb, int b_is_nt, float* C, long ldc, int M, int N, int K,
                   const float* bias, const float* addend, long add_ld, void* stream);
 

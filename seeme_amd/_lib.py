@@ -152,6 +152,7 @@ _SIGNATURES = {
     "seeme_glue_mid": (C.c_int, [C.POINTER(GlueMid), fp]),
     "seeme_grouped_gemm": (C.c_int, [fp, C.c_int, C.c_int, fp]),
     "seeme_gemm_problem_bytes": (C.c_int, []),
+    "seeme_wgrad128": (C.c_int, [fp, C.c_long, fp, C.c_long, C.c_int, C.c_int, C.c_int, fp, C.c_long, fp, fp]),
     "seeme_gemm128": (C.c_int, [fp, C.c_long, fp, C.c_long, C.c_int, fp, C.c_long, C.c_int, C.c_int, C.c_int, fp, fp, C.c_long, fp]),
     "seeme_version": (C.c_int, []),
     "seeme_last_error": (C.c_char_p, []),

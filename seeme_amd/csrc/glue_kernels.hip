@@ -555,3 +555,115 @@ extern "C" int seeme_gemm128(const float* A, long lda, const float* B, long ldb,
     }
     return seeme_check_launch("k_gemm128");
 }
+
+// ------------------------------------------------------------------ large weight gradient (the stage-1 step's dW = dY^T X)
+// G[Nout,Kin] += sum_m dY[m,n] X[m,k], gbias[n] += sum_m dY[m,n]: the reduction runs over the M = B x S token rows, the output
+// is a small matrix, so the rows are split into chunks (one workgroup per 128 x 128 output tile and chunk) that accumulate with
+// atomics.  Both operands are read along their contiguous dimension (dwordx4) and land in LDS without a transposition
+// (As[m][n], Bs[m][k]: float4 writes); the row guard of the last chunk is a select on address and value.
+__global__ __launch_bounds__(256, 2) void k_wgrad128(const float* __restrict__ dY, long ldy, const float* __restrict__ X, long ldx,
+                                                     int M, int chunk_rows, float* __restrict__ G, long ldg, int tiles_k,
+                                                     int n_out_tiles, float* __restrict__ gbias) {
+    constexpr int LD = 132;
+    extern __shared__ __attribute__((aligned(16))) float g1_smem[];
+    float (*As)[32][LD] = reinterpret_cast<float (*)[32][LD]>(g1_smem);
+    float (*Bs)[32][LD] = reinterpret_cast<float (*)[32][LD]>(g1_smem + 2 * 32 * LD);
+    __shared__ float csr[8][128];
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63, wi = wv >> 1, wj = wv & 1;
+    const int tile = blockIdx.x % (n_out_tiles * tiles_k), chunk = blockIdx.x / (n_out_tiles * tiles_k);
+    const int n0 = (tile / tiles_k) * 128, k0c = (tile % tiles_k) * 128;
+    const int m_lo = chunk * chunk_rows, m_hi = min(M, m_lo + chunk_rows);
+    if (m_lo >= m_hi) return;
+    const gfloat* Ap = (const gfloat*)dY + n0;
+    const gfloat* Bp = (const gfloat*)X + k0c;
+    g1_f32x4 ra[4], rb[4];
+    float cs4[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_cs = gbias != nullptr && k0c == 0;
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int m = m0 + (t >> 5) + 8 * g;
+            const bool ok = m < m_hi;
+            const long mm = ok ? m : m_lo;
+            ra[g] = *(const g1_gfloat4*)(Ap + mm * ldy + 4 * (t & 31));
+            rb[g] = *(const g1_gfloat4*)(Bp + mm * ldx + 4 * (t & 31));
+            if (!ok) { ra[g] = g1_f32x4{0.f, 0.f, 0.f, 0.f}; rb[g] = g1_f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<g1_f32x4*>(&As[buf][(t >> 5) + 8 * g][4 * (t & 31)]) = ra[g];
+            *reinterpret_cast<g1_f32x4*>(&Bs[buf][(t >> 5) + 8 * g][4 * (t & 31)]) = rb[g];
+            cs4[0] += ra[g].x; cs4[1] += ra[g].y; cs4[2] += ra[g].z; cs4[3] += ra[g].w;
+        }
+    };
+    g1_f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[x][y][v] = 0.f;
+    fetch(m_lo);
+    stage(0);
+    __syncthreads();
+    const int nk = (m_hi - m_lo + 31) / 32;
+    for (int s = 0; s < nk; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nk) fetch(m_lo + 32 * (s + 1));
+        const float* ap0 = &As[buf][ln >> 5][64 * wi + (ln & 31)];
+        const float* bp0 = &Bs[buf][ln >> 5][64 * wj + (ln & 31)];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float fa[2], fb[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) { fa[x] = ap0[2 * q * LD + 32 * x]; fb[x] = bp0[2 * q * LD + 32 * x]; }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x], fb[y], acc[x][y], 0, 0, 0);
+        }
+        if (s + 1 < nk) stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const long ib = n0 + 64 * wi + 32 * x + 4 * (ln >> 5), j = k0c + 64 * wj + 32 * y + (ln & 31);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) atomicAdd(G + (ib + 8 * (v >> 2) + (v & 3)) * ldg + j, acc[x][y][v]);
+        }
+    if (want_cs) {                       // thread (t & 31, t >> 5) holds the column sums of n = 4 (t & 31) + c over its rows
+#pragma unroll
+        for (int c = 0; c < 4; ++c) csr[t >> 5][4 * (t & 31) + c] = cs4[c];
+        __syncthreads();
+        if (t < 128) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) v += csr[g][t];
+            atomicAdd(gbias + n0 + t, v);
+        }
+    }
+}
+
+extern "C" int seeme_wgrad128(const float* dY, long ldy, const float* X, long ldx, int M, int Nout, int Kin, float* G, long ldg,
+                              float* gbias, void* stream) {
+    if (!dY || !X || !G || M < 1 || Nout < 128 || Kin < 128 || (Nout & 127) || (Kin & 127) || (ldy & 3) || (ldx & 3) ||
+        ((size_t)dY & 15) || ((size_t)X & 15))
+        return seeme_fail("seeme_wgrad128: Nout, Kin multiples of 128, 16-byte aligned operands with strides in multiples of 4");
+    const int n_out_tiles = Nout / 128, tiles_k = Kin / 128, tiles = n_out_tiles * tiles_k;
+    // enough chunks to fill the chip twice over, at least 64 rows (2 k-steps) each, whole k-steps
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("SEEME_WGRAD_WGS"); target = e ? atoi(e) : 512; if (target < 1) target = 1; }
+    int nchunk = (target + tiles - 1) / tiles;
+    int chunk_rows = ((M + nchunk - 1) / nchunk + 31) / 32 * 32;
+    if (chunk_rows < 64) chunk_rows = 64;
+    nchunk = (M + chunk_rows - 1) / chunk_rows;
+    const size_t lds = (size_t)4 * 32 * 132 * 4;
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_wgrad128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_wgrad128, dim3(tiles * nchunk), dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, M, chunk_rows, G, ldg,
+                       tiles_k, n_out_tiles, gbias);
+    return seeme_check_launch("k_wgrad128");
+}

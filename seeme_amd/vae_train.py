@@ -80,6 +80,16 @@ class _Ops:
         else:
             self.gemm(_gemm_dgrad(A, lda, B, ldb, K, N, Cp, ldc, M, bias=bias, addend=addend, add_ld=add_ld))
 
+    def wgrad(self, dy, ldy, x, ldx, S, B, g, ldg, Nout, Kin, gbias=0):
+        """g[Nout,Kin] += dY^T X over the B * S token rows, gbias += column sums of dY: the specialised kernel when the output is
+        a multiple of 128 x 128, else a split reduction of the grouped GEMM (one member per sequence)."""
+        if Nout % 128 == 0 and Kin % 128 == 0 and ldy % 4 == 0 and ldx % 4 == 0 and dy % 16 == 0 and x % 16 == 0 \
+                and os.environ.get("SEEME_GEMM128", "1") != "0":
+            self.ops.append(lambda: L.check(L.lib().seeme_wgrad128(dy, ldy, x, ldx, B * S, Nout, Kin, g, ldg, gbias, L.current_stream()),
+                                            "seeme_wgrad128"))
+        else:
+            self.gemm(_gemm_wgrad(dy, ldy, x, ldx, S, B, g, ldg, Nout, Kin, gbias))
+
     def add_ln(self, sub, res, norm, y, xhat, rstd, M, sub_seq_rows=0):
         a = L.VtLn()
         a.sub, a.res, a.gamma, a.beta, a.y, a.xhat, a.rstd = sub, res, P(norm.weight), P(norm.bias), y, xhat, rstd
@@ -262,12 +272,12 @@ class _StackPlan:
             ops.dropout(P(self.G2), P(sv["m2"]), ds, P(self.Gm), M * 256)
             g2 = P(self.Gm)
         ops.plain(g2, 256, P(lp.linear2.weight), 128, False, P(self.dh), 128, M, 128, 256)
-        ops.gemm(_gemm_wgrad(g2, 256, P(sv["h"]), 128, S, B, G(lp.linear2.weight), 128, 256, 128, G(lp.linear2.bias)))
+        ops.wgrad(g2, 256, P(sv["h"]), 128, S, B, G(lp.linear2.weight), 128, 256, 128, G(lp.linear2.bias))
         if dr:
             ops.dropout(P(self.dh), P(sv["mh"]), ds, P(self.dh), M * 128)
         ops.call(lambda: L.check(L.lib().seeme_vt_gelu(P(sv["hpre"]), P(self.dh), P(self.dhpre), M * 128, L.current_stream()), "seeme_vt_gelu"))
         ops.plain(P(self.dhpre), 128, P(lp.linear1.weight), 256, False, P(self.DX1), 256, M, 256, 128, addend=P(self.G2), add_ld=256)
-        wg = [_gemm_wgrad(P(self.dhpre), 128, x1, 256, S, B, G(lp.linear1.weight), 256, 128, 256, G(lp.linear1.bias))]
+        ops.wgrad(P(self.dhpre), 128, x1, 256, S, B, G(lp.linear1.weight), 256, 128, 256, G(lp.linear1.bias))
         d_x1 = P(self.DX1)
         if self.dec:
             ca = lp.multihead_attn
@@ -294,7 +304,7 @@ class _StackPlan:
             ops.dropout(P(self.G1), P(sv["m1"]), ds, P(self.Gm), M * 256)
             g1 = P(self.Gm)
         ops.plain(g1, 256, P(sa.out_proj.weight), 256, False, P(self.dO), 256, M, 256, 256)
-        ops.gemm(_gemm_wgrad(g1, 256, P(sv["O"]), 256, S, B, G(sa.out_proj.weight), 256, 256, 256, G(sa.out_proj.bias)))
+        ops.wgrad(g1, 256, P(sv["O"]), 256, S, B, G(sa.out_proj.weight), 256, 256, 256, G(sa.out_proj.bias))
         q, dq = P(sv["qkv"]), P(self.dqkv)
         pv = P(sv["Pd"]) if dr else P(sv["P"])
         ops.gemm(_prob([P(self.dO)], [q + 4 * 512], [256], [1], [1], 256, 768, P(self.dP), S, S, S, nbatch=B, bstrides=(S * 256, S * 768, S * S)),
@@ -306,8 +316,7 @@ class _StackPlan:
         ops.gemm(_prob([P(self.dP)], [q + 4 * 256], [S], [1], [768], S, 1, dq, 768, S, 256, nbatch=B, bstrides=(S * S, S * 768, S * 768)),
                  _prob([P(self.dP)], [q], [S], [S], [768], 1, 1, dq + 4 * 256, 768, S, 256, nbatch=B, bstrides=(S * S, S * 768, S * 768)))
         ops.plain(dq, 768, P(sa.in_proj_weight), 256, False, out, 256, M, 256, 768, addend=P(self.G1), add_ld=256)
-        wg += [_gemm_wgrad(dq, 768, x_in, 256, S, B, G(sa.in_proj_weight), 256, 768, 256, G(sa.in_proj_bias))]
-        ops.gemm(*wg)
+        ops.wgrad(dq, 768, x_in, 256, S, B, G(sa.in_proj_weight), 256, 768, 256, G(sa.in_proj_bias))
 
     def record_backward(self):
         params = [p for p in self.params() if p.requires_grad]
@@ -333,14 +342,16 @@ class _StackPlan:
         lin = self.lins[1]                                                      # xs[1] = W [x2[3] | x2[0]] + b
         ops.gemm(_gemm_dgrad(Bb, 256, P(lin.weight), 512, 256, 256, A, 256, M),
                  _gemm_dgrad(Bb, 256, P(lin.weight) + 4 * 256, 512, 256, 256, P(self.SK[0]), 256, M),
-                 _gemm_wgrad(Bb, 256, x2[3], 256, S, B, G(lin.weight), 512, 256, 256, G(lin.bias)),
-                 _gemm_wgrad(Bb, 256, x2[0], 256, S, B, G(lin.weight) + 4 * 256, 512, 256, 256))
+                 )
+        ops.wgrad(Bb, 256, x2[3], 256, S, B, G(lin.weight), 512, 256, 256, G(lin.bias))
+        ops.wgrad(Bb, 256, x2[0], 256, S, B, G(lin.weight) + 4 * 256, 512, 256, 256)
         self._layer_bwd(ops, 3, P(self.xs[0]), A, 0, Bb)                       # Bb = d xs[0]
         lin = self.lins[0]                                                      # xs[0] = W [x2[2] | x2[1]] + b
         ops.gemm(_gemm_dgrad(Bb, 256, P(lin.weight), 512, 256, 256, A, 256, M),
                  _gemm_dgrad(Bb, 256, P(lin.weight) + 4 * 256, 512, 256, 256, P(self.SK[1]), 256, M),
-                 _gemm_wgrad(Bb, 256, x2[2], 256, S, B, G(lin.weight), 512, 256, 256, G(lin.bias)),
-                 _gemm_wgrad(Bb, 256, x2[1], 256, S, B, G(lin.weight) + 4 * 256, 512, 256, 256))
+                 )
+        ops.wgrad(Bb, 256, x2[2], 256, S, B, G(lin.weight), 512, 256, 256, G(lin.bias))
+        ops.wgrad(Bb, 256, x2[1], 256, S, B, G(lin.weight) + 4 * 256, 512, 256, 256)
         self._layer_bwd(ops, 2, x2[1], A, 0, Bb)                                # Bb = d x2[1] (+ SK[1])
         self._layer_bwd(ops, 1, x2[0], Bb, P(self.SK[1]), A)                    # A = d x2[0] (+ SK[0])
         self._layer_bwd(ops, 0, P(self.x0), A, P(self.SK[0]), Bb)               # Bb = d x0
