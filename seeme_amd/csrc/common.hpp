@@ -253,6 +253,66 @@ __device__ __forceinline__ float4 wave_layernorm256(float4 v, const LnParams& p,
     return make_float4(c.x * rs * p.w.x + p.b.x, c.y * rs * p.w.y + p.b.y, c.z * rs * p.w.z + p.b.z,
                        c.w * rs * p.w.w + p.b.w);
 }
+// The same for the 8 rows a wave owns at once.  Eight independent 64-lane reductions cost 8 x (4 DPP steps + 4 readlanes) and
+// the compiler runs them one after another (measured in k_layer_h: 550 cycles per row, 40 % of the kernel in its two
+// LayerNorm phases); a reduce-scatter over the rows halves the number of live values per exchange step instead:
+// v_permlane32_swap (8 -> 4 values), v_permlane16_swap (4 -> 2), row_ror:8 (2 -> 1), then three 8-lane butterfly steps.
+// wave_sum8 returns in lane l the 64-lane total of s[l >> 3]; readlane(8 j) hands row j's total to every lane as a scalar.
+__device__ __forceinline__ float swap_add32(float a, float b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float dpp_f(float v, const int ctrl_b1_4e_141_128) {
+    const int iv = __float_as_int(v);
+    return __int_as_float(ctrl_b1_4e_141_128 == 0 ? __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xF, 0xF, true)
+                        : ctrl_b1_4e_141_128 == 1 ? __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xF, 0xF, true)
+                        : ctrl_b1_4e_141_128 == 2 ? __builtin_amdgcn_update_dpp(0, iv, 0x141, 0xF, 0xF, true)
+                                                  : __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum8(const float (&s)[8]) {
+    const float t0 = swap_add32(s[0], s[4]), t1 = swap_add32(s[1], s[5]), t2 = swap_add32(s[2], s[6]), t3 = swap_add32(s[3], s[7]);
+    const float u0 = swap_add16(t0, t2), u1 = swap_add16(t1, t3);
+    const bool hi = (threadIdx.x & 8) != 0;
+    float w = (hi ? u1 : u0) + dpp_f(hi ? u0 : u1, 3);
+    w += dpp_f(w, 0);
+    w += dpp_f(w, 1);
+    w += dpp_f(w, 2);
+    return w;
+}
+__device__ __forceinline__ float lane8(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 8 * j)); }
+__device__ __forceinline__ void wave_layernorm256_x8(float4 (&v)[8], const LnParams& p, float eps) {
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const float mean = wave_sum8(s) * (1.f / 256.f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float m = lane8(mean, j);
+        v[j] = make_float4(v[j].x - m, v[j].y - m, v[j].z - m, v[j].w - m);
+        s[j] = (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+    }
+    const float rsl = 1.f / sqrtf(wave_sum8(s) * (1.f / 256.f) + eps);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float rs = lane8(rsl, j);
+        v[j] = make_float4(v[j].x * rs * p.w.x + p.b.x, v[j].y * rs * p.w.y + p.b.y, v[j].z * rs * p.w.z + p.b.z, v[j].w * rs * p.w.w + p.b.w);
+    }
+}
+// LayerNorm parameters that may be absent: always loaded (from `safe` when the pointer is null) and selected afterwards -- a
+// load under `p != nullptr ? ... : ...` is a branch + load + vmcnt(0), one serialised round trip per parameter vector.
+__device__ __forceinline__ LnParams ln_params256_opt(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ safe) {
+    const int lane = threadIdx.x & 63;
+    const float4 wv = *reinterpret_cast<const float4*>((w != nullptr ? w : safe) + lane * 4);
+    const float4 bv = *reinterpret_cast<const float4*>((b != nullptr ? b : safe) + lane * 4);
+    LnParams p;
+    p.w = w != nullptr ? wv : make_float4(1.f, 1.f, 1.f, 1.f);
+    p.b = b != nullptr ? bv : make_float4(0.f, 0.f, 0.f, 0.f);
+    return p;
+}
 __device__ __forceinline__ float4 wave_layernorm256(float4 v, const float* __restrict__ w,
                                                     const float* __restrict__ b, float eps) {
     const int lane = threadIdx.x & 63;

@@ -41,7 +41,7 @@ extern "C" int seeme_debug_h16_times(unsigned long long* host, int n) {
 #define H16_DBG(k, i) do {} while (0)
 #endif
 #ifndef H16_PF
-#define H16_PF 2      // k-blocks of weight fragments in flight in the tile GEMMs (measured: 4 is no faster)
+#define H16_PF 4      // k-blocks of weight fragments in flight in the tile GEMMs (2 -> 4: 1 % of a B=256 pass; the tiles are bound by L2 -> L1 bytes)
 #endif
 #ifndef FFN_PF
 #define FFN_PF H16_PF  // the FFN's first GEMM (2 n-tiles per wave)
@@ -72,46 +72,75 @@ __device__ __forceinline__ void tile_gemm_h16(const unsigned short* __restrict__
     uint4 ab[2][MTL];
 #pragma unroll
     for (int mt = 0; mt < MTL; ++mt) ab[0][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda);
-    for (int kb0 = 0; kb0 < K32; kb0 += PF) {
+    // Every k-block of the main loop re-fills its slot UNCONDITIONALLY, the last PF k-blocks (peeled) re-fill nothing: with
+    // the re-fill under `if (kb + PF < K32)` the number of loads in flight at the next wait is not a compile-time fact, the
+    // compiler assumes the smaller one and emits vmcnt(NTL-1 .. 0) -- which, vmcnt being in-order, waits for the re-fill just
+    // issued: one full L2 round trip per k-block whatever the ring depth (this is why depths 2 and 4 measured the same).
+    const int K32r = (K32 + PF - 1) / PF * PF;
+    int kb0 = 0;
+    for (; kb0 + PF < K32r; kb0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int kb = kb0 + u;
-            if (kb < K32) {
-                const int ka = (kb + 1 < K32) ? kb + 1 : kb;
+            const int kb = kb0 + u;                          // < K32 - 1 here
 #pragma unroll
-                for (int mt = 0; mt < MTL; ++mt) ab[(u + 1) & 1][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda + ka * 32);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int mt = 0; mt < MTL; ++mt) ab[(u + 1) & 1][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda + (kb + 1) * 32);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < MTL; ++mt)
+            for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NTL; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, ab[u & 1][mt]), __builtin_bit_cast(h16x8, br[u][nt]), acc[mt][nt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kb + PF < K32) {
+                for (int nt = 0; nt < NTL; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, ab[u & 1][mt]), __builtin_bit_cast(h16x8, br[u][nt]), acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = kb + PF < K32 ? kb + PF : K32 - 1;
 #pragma unroll
-                    for (int nt = 0; nt < NTL; ++nt) br[u][nt] = loadb(nt, kb + PF);
-                }
-            }
+            for (int nt = 0; nt < NTL; ++nt) br[u][nt] = loadb(nt, kn);
         }
     }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int kb = kb0 + u;
+        const int ka = (kb + 1 < K32) ? kb + 1 : K32 - 1;
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt) ab[(u + 1) & 1][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda + ka * 32);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb < K32) {
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, ab[u & 1][mt]), __builtin_bit_cast(h16x8, br[u][nt]), acc[mt][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
-// B fragments from fragment-packed weights: Wp[(ntile*kstride + kb)*64 + lane]; n-tiles clamped to ntiles-1
+// B fragments from fragment-packed weights: Wp[(ntile*kstride + kb)*64 + lane]; n-tiles clamped to ntiles-1.  Buffer loads:
+// one descriptor per matrix, the lane's 16-byte offset in a VGPR, (n-tile, k-block) as a SCALAR byte offset -- no 64-bit
+// per-lane address arithmetic and half the address traffic of global_load (PACKED_GLOBAL_LOADS=1 keeps the old form).
+#ifndef PACKED_GLOBAL_LOADS
+#define PACKED_GLOBAL_LOADS 0
+#endif
+struct PackedSrc {
+    __amdgpu_buffer_rsrc_t rs; const uint4* wp; int kstride, ntile0, ntiles; unsigned voff;
+    __device__ __forceinline__ PackedSrc(const uint4* __restrict__ Wp, int kstride_, int ntile0_, int ntiles_)
+        : rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(Wp), 0, 0x7FFFFFF0, 0x00020000)), wp(Wp), kstride(kstride_),
+          ntile0(__builtin_amdgcn_readfirstlane(ntile0_)), ntiles(ntiles_), voff((threadIdx.x & 63) * 16u) {}
+    __device__ __forceinline__ uint4 operator()(int nt, int kb) const {
+        int t = ntile0 + nt; t = t < ntiles ? t : ntiles - 1;
+#if PACKED_GLOBAL_LOADS
+        return wp[((size_t)t * kstride + kb) * 64 + (threadIdx.x & 63)];
+#else
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)(t * kstride + kb) * 1024u, 0));
+#endif
+    }
+};
 template <int MTL, int NTL, int PF = H16_PF>
 __device__ __forceinline__ void gemm_packed(const unsigned short* As, int lda, const uint4* __restrict__ Wp, int kstride,
                                             int ntile0, int ntiles, int K32, f32x4 (&acc)[MTL][NTL], BRing<NTL, PF>& ring) {
-    const int lane = threadIdx.x & 63;
-    tile_gemm_h16<MTL, NTL, PF>(As, lda, K32, [&](int nt, int kb) {
-        int t = ntile0 + nt; t = t < ntiles ? t : ntiles - 1;
-        return Wp[((size_t)t * kstride + kb) * 64 + lane];
-    }, acc, ring);
+    tile_gemm_h16<MTL, NTL, PF>(As, lda, K32, PackedSrc(Wp, kstride, ntile0, ntiles), acc, ring);
 }
 template <int NTL, int PF = H16_PF>
 __device__ __forceinline__ void prime_packed(BRing<NTL, PF>& ring, const uint4* __restrict__ Wp, int kstride, int ntile0, int ntiles, int K32) {
-    const int lane = threadIdx.x & 63;
-    ring_prime(ring, K32, [&](int nt, int kb) {
-        int t = ntile0 + nt; t = t < ntiles ? t : ntiles - 1;
-        return Wp[((size_t)t * kstride + kb) * 64 + lane];
-    });
+    ring_prime(ring, K32, PackedSrc(Wp, kstride, ntile0, ntiles));
 }
 template <int MTL, int NTL, int PF = H16_PF>
 __device__ __forceinline__ void gemm_packed(const unsigned short* As, int lda, const uint4* __restrict__ Wp, int kstride,
@@ -489,7 +518,7 @@ struct AttnHArgs {
 };
 
 #ifndef ATT_PF
-#define ATT_PF 2    // k-blocks of B operands (K rows, V^T rows, W_o) in flight: the tile is latency-bound, not MFMA-bound
+#define ATT_PF 4    // k-blocks of B operands (K rows, V^T rows, W_o) in flight: the tile is latency-bound, not MFMA-bound
 #endif
 template <int NC>      // NC = Sp / 64 score columns per lane
 __device__ __forceinline__ void attn_softmax_rows(const float* Ps, int ldp, unsigned short* Ph, int ldph, int wave, int lane) {
@@ -751,11 +780,14 @@ static int launch_ffn_h(const FfnHArgs& a, hipStream_t st) {
 // LDS: R0 = [32][Sp+8] fp32 (scores -> out_proj tile -> hidden operand -> FFN output tile -> tail tiles), R1 = [32][272]
 // fp16 (Q -> O -> x operand -> hidden -> x operand): 51 KB at Sp = 256, three workgroups per CU.  LN1's output rows stay in
 // registers (8 float4 per lane) as the FFN residual.
+#ifndef LAYER_KV_PF
+#define LAYER_KV_PF 4    // k-blocks of K rows / V^T rows in flight in k_layer_h's two attention GEMMs
+#endif
 #ifndef LAYER_WPE
 #define LAYER_WPE 2      // workgroups per CU the register allocation aims at (3 would need <= 168 VGPRs)
 #endif
 struct LayerHArgs {
-    const unsigned short* qk; const unsigned short* vt; const float* res;
+    const unsigned short* q; const uint4* kp; const uint4* vp; const float* res;   // q rows [B*S][256]; keys / values fragment-packed (below)
     const uint4* wo; const float* bo; const float* n1_w; const float* n1_b;
     const int32_t* lengths;
     int S, n_prefix, q_rows, Sp, spv; float scale, eps;
@@ -764,7 +796,7 @@ struct LayerHArgs {
     const float* fin_w; const float* fin_b;
     float* out; int out_mode, B;
     const uint4* skip_w; const float* skip_b; const float* skip_src; float* xnext;
-    const uint4* qkv_w; const float* qkv_b; unsigned short* qk_out; unsigned short* vt_out;
+    const uint4* qkv_w; const float* qkv_b; unsigned short* q_out; uint4* kp_out; uint4* vp_out;
     const uint4* proj_w; const float* proj_b; float* feats; int F;
 };
 
@@ -773,14 +805,21 @@ __device__ __forceinline__ void rows_to_h16(unsigned short* Xh, int ldh, int row
     *reinterpret_cast<uint2*>(Xh + row * ldh + lane * 4) = make_uint2(lo, hi);
 }
 
-// q | k | V^T of a 32-row tile (fp16 operand rows in Xh) for the layer that runs next: q | k as fp16 rows, V transposed; the
-// padding columns [S, spv) of V^T are written as zeros (the tiles of a sequence cover them), so no memset is needed.
+// q | K | V of a 32-row tile (fp16 operand rows in Xh) for the layer that runs next.  q: fp16 rows [B*S][256].  Keys and values
+// leave in the order the attention GEMMs of the next launch read them as MFMA B operands -- one contiguous KiB per wave-load:
+//   kp[((b*NT16 + key/16)*8 + d/32)*64 + ((d%32)/8)*16 + key%16]   = K[key][8 dims from 8*(d/8)]            (NT16 = ceil(S/16))
+//   vp[((b*16 + d/16)*KB + key/32)*64 + ((key%32)/8)*16 + d%16]    = V[8 keys from 8*(key/8)][d]            (KB = spv/32)
+// (row-major K rows / V^T rows made every wave-load touch 16 rows x 64 B; the V^T rows were written two bytes at a time).
+// Value granules of keys in [S, spv) are written as zeros by the tiles that cover them (P = 0 there, but 0 x garbage is not);
+// key rows in [S, 16 NT16) stay unwritten: their score columns are masked by a select.
 __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned short* Oh, const uint4* __restrict__ qkv_w,
-                                              const float* __restrict__ qkv_b, unsigned short* __restrict__ qk_out,
-                                              unsigned short* __restrict__ vt_out, int b, int q0, int S, int spv, BRing<4, H16_PF>& ring_t) {
+                                              const float* __restrict__ qkv_b, unsigned short* __restrict__ q_out,
+                                              uint4* __restrict__ kp_out, uint4* __restrict__ vp_out, int b, int q0, int S, int spv,
+                                              BRing<4, H16_PF>& ring_t) {
     const int tid = threadIdx.x, wave = tid >> 6;
     const int ldq = 256 + HPAD;
     const size_t base = (size_t)b * S;
+    const int NT16 = (S + 15) >> 4, KB = spv >> 5;
     for (int y = 0; y < 3; ++y) {
         f32x4 acc[2][4];
         acc_zero(acc);
@@ -790,25 +829,40 @@ __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned
         __syncthreads();                    // the previous part's stores have read the output tile
         acc_store_h16<2, 4>(acc, Oh, ldq, wave * 64, bias, SEEME_ACT_NONE);
         __syncthreads();
-        if (y < 2) {
-            for (int idx = tid; idx < TILE_M * 32; idx += 256) {
-                const int row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
-                if (s < S) *reinterpret_cast<uint4*>(qk_out + (base + s) * 512 + y * 256 + c8) = *reinterpret_cast<const uint4*>(Oh + row * ldq + c8);
+        if (y == 0) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = tid + it * 256, row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
+                if (s < S) *reinterpret_cast<uint4*>(q_out + (base + s) * 256 + c8) = *reinterpret_cast<const uint4*>(Oh + row * ldq + c8);
             }
-        } else {                            // V^T [b][d][s]: lanes <-> rows
-            const int row = tid & 31, dg = tid >> 5, s = q0 + row;
-            if (s < spv) {
-                unsigned short* vb = vt_out + ((size_t)b * 256) * spv + s;
-#pragma unroll 8
-                for (int j = 0; j < 32; ++j) {
-                    const int d = dg * 32 + j;
-                    vb[(size_t)d * spv] = s < S ? Oh[row * ldq + d] : (unsigned short)0;
+        } else if (y == 1) {
+            uint4* kb_out = kp_out + ((size_t)b * NT16 + (q0 >> 4)) * 512;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = tid + it * 256, r = idx & 15, kq = (idx >> 4) & 3, kb = (idx >> 6) & 7, half = idx >> 9, row = half * 16 + r;
+                if (q0 + row < S) kb_out[(half * 8 + kb) * 64 + kq * 16 + r] = *reinterpret_cast<const uint4*>(Oh + row * ldq + kb * 32 + kq * 8);
+            }
+        } else {
+            uint4* vb_out = vp_out + (size_t)b * 16 * KB * 64 + (size_t)(q0 >> 5) * 64;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = tid + it * 256, r = idx & 15, g = (idx >> 4) & 3, nt = idx >> 6;
+                const unsigned short* src = Oh + (8 * g) * ldq + nt * 16 + r;
+                unsigned w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int s0 = q0 + 8 * g + 2 * j;
+                    const unsigned lo = s0 < S ? src[(2 * j) * ldq] : 0u, hi = s0 + 1 < S ? src[(2 * j + 1) * ldq] : 0u;
+                    w[j] = lo | (hi << 16);
                 }
+                vb_out[(size_t)nt * KB * 64 + g * 16 + r] = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
     }
 }
 
+// debug stamps of a layer that has the next layer's QKV as its tail (the last launch of those in a pass is what is read back)
+#define LAYER_DBG(i) do { if (a.qkv_w != nullptr) H16_DBG(5, i); } while (0)
 __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
@@ -830,12 +884,13 @@ __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) 
     const BiasRegs<4> bias_o = bias_load<4>(a.bo, wave * 64, 256);
     BRing<4, ATT_PF> ring_o;
     prime_packed(ring_o, a.wo, 8, wave * 4, 16, 8);
+    LAYER_DBG(0);
     {   // Q tile
         uint4 qv[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = tid + it * 256, row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
-            qv[it] = *reinterpret_cast<const uint4*>(a.qk + (base + (s < a.q_rows ? s : 0)) * 512 + c8);
+            qv[it] = *reinterpret_cast<const uint4*>(a.q + (base + (s < a.q_rows ? s : 0)) * 256 + c8);
             if (s >= a.q_rows) qv[it] = make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
@@ -845,12 +900,14 @@ __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) 
         }
     }
     __syncthreads();
-    const unsigned short* Kmat = a.qk + base * 512 + 256;
+    LAYER_DBG(1);
+    const int NT16 = (a.S + 15) >> 4;
+    const uint4* Kp = a.kp + (size_t)b * NT16 * 512;
     for (int c0 = 0; c0 < a.Sp; c0 += CH_N) {
         const int n0 = c0 + wave * 64;
         f32x4 acc[2][4];
         acc_zero(acc);
-        if (n0 < a.S) gemm_rows<2, 4, ATT_PF>(Qh, ldq, Kmat, 512, n0, a.S, 8, acc);
+        if (n0 < a.S) gemm_packed<2, 4, LAYER_KV_PF>(Qh, ldq, Kp, 8, n0 >> 4, NT16, 8, acc);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int c = n0 + nt * 16 + r;
@@ -862,17 +919,20 @@ __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) 
         }
     }
     __syncthreads();
+    LAYER_DBG(2);
     if (a.Sp == 256) attn_softmax_rows<4>(Ps, ldp, Ph, ldph, wave, lane);
     else attn_softmax_rows<8>(Ps, ldp, Ph, ldph, wave, lane);
     __syncthreads();
+    LAYER_DBG(3);
     {   // O = P V
         f32x4 acc[2][4];
         acc_zero(acc);
         const int K32 = (n_valid_keys + 31) >> 5;
-        gemm_rows<2, 4, ATT_PF>(Ph, ldph, a.vt + (size_t)b * 256 * a.spv, a.spv, wave * 64, 256, K32, acc);
+        gemm_packed<2, 4, LAYER_KV_PF>(Ph, ldph, a.vp + (size_t)b * 16 * (a.spv >> 5) * 64, a.spv >> 5, wave * 4, 16, K32, acc);
         acc_store_h16<2, 4>(acc, Qh, ldq, wave * 64, nullptr, SEEME_ACT_NONE);
     }
     __syncthreads();
+    LAYER_DBG(4);
     float* Cs = R0;
     {
         f32x4 acc[2][4];
@@ -888,35 +948,44 @@ __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) 
     prime_packed(ring1, a.w1, 8, wave * 2, 8, 8);
     prime_packed(ring2, a.w2, 4, wave * 4, 16, 4);
     __syncthreads();
+    LAYER_DBG(5);
     unsigned short* Xh = R1;
     float4 x1[8];
     {   // +residual, LN1 [, + cross-attention vector, LN]; rows stay in registers, fp16 copy is the FFN operand
-        const LnParams lp = ln_params256(a.n1_w, a.n1_b), lc = ln_params256(a.lnc_w, a.lnc_b);
+        const LnParams lp = ln_params256_opt(a.n1_w, a.n1_b, a.n1_w), lc = ln_params256_opt(a.lnc_w, a.lnc_b, a.n1_w);
         float4 xr[8];
-        float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.cvec != nullptr) cv = *reinterpret_cast<const float4*>(a.cvec + (size_t)b * a.cvec_ld + lane * 4);
+        const float4 cv = *reinterpret_cast<const float4*>((a.cvec != nullptr ? a.cvec + (size_t)b * a.cvec_ld : a.n1_w) + lane * 4);
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const int s = q0 + wave * 8 + rr;
             xr[rr] = *reinterpret_cast<const float4*>(a.res + (base + (s < a.q_rows ? s : 0)) * 256 + lane * 4);
         }
         __builtin_amdgcn_sched_barrier(0);
+        LAYER_DBG(16);
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
-            const int row = wave * 8 + rr, s = q0 + row;
-            float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + lane * 4);
-            v = make_float4(v.x + xr[rr].x, v.y + xr[rr].y, v.z + xr[rr].z, v.w + xr[rr].w);
-            v = wave_layernorm256(v, lp, a.eps);
-            if (a.cvec != nullptr) {
-                v = make_float4(v.x + cv.x, v.y + cv.y, v.z + cv.z, v.w + cv.w);
-                v = wave_layernorm256(v, lc, a.eps);
-            }
-            if (s >= a.q_rows) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            x1[rr] = v;
-            rows_to_h16(Xh, ldq, row, lane, v);
+            const float4 v = *reinterpret_cast<const float4*>(Cs + (wave * 8 + rr) * ldc + lane * 4);
+            x1[rr] = make_float4(v.x + xr[rr].x, v.y + xr[rr].y, v.z + xr[rr].z, v.w + xr[rr].w);
         }
+        LAYER_DBG(17);
+        wave_layernorm256_x8(x1, lp, a.eps);
+        LAYER_DBG(18);
+        if (a.cvec != nullptr) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) x1[rr] = make_float4(x1[rr].x + cv.x, x1[rr].y + cv.y, x1[rr].z + cv.z, x1[rr].w + cv.w);
+            wave_layernorm256_x8(x1, lc, a.eps);
+        }
+        LAYER_DBG(19);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr;
+            if (q0 + row >= a.q_rows) x1[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rows_to_h16(Xh, ldq, row, lane, x1[rr]);
+        }
+        LAYER_DBG(20);
     }
     __syncthreads();
+    LAYER_DBG(6);
     unsigned short* Hh = R1;                     // hidden [32][144] overwrites the operand once every wave has read it
     const int ldhh = 128 + HPAD;
     {
@@ -927,6 +996,7 @@ __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) 
         acc_store_h16<2, 2>(acc1, Hh, ldhh, wave * 32, bias1, SEEME_ACT_GELU);
     }
     __syncthreads();
+    LAYER_DBG(7);
     {
         f32x4 acc2[2][4];
         acc_zero(acc2);
@@ -940,23 +1010,29 @@ __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) 
     else if (a.qkv_w != nullptr) prime_packed(ring_t, a.qkv_w, 8, wave * 4, 48, 8);
     else if (a.proj_w != nullptr) prime_packed(ring_t, a.proj_w, 8, wave * 4, (a.F + 15) >> 4, 8);
     __syncthreads();
+    LAYER_DBG(8);
     {   // +residual, LN [, stack LN]; layer output rows
-        const LnParams lp = ln_params256(a.n2_w, a.n2_b), lf = ln_params256(a.fin_w, a.fin_b);
+        const LnParams lp = ln_params256_opt(a.n2_w, a.n2_b, a.n2_w), lf = ln_params256_opt(a.fin_w, a.fin_b, a.n2_w);
+        float4 v[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const float4 c = *reinterpret_cast<const float4*>(Cs + (wave * 8 + rr) * ldc + lane * 4);
+            v[rr] = make_float4(c.x + x1[rr].x, c.y + x1[rr].y, c.z + x1[rr].z, c.w + x1[rr].w);
+        }
+        wave_layernorm256_x8(v, lp, a.eps);
+        if (a.fin_w != nullptr) wave_layernorm256_x8(v, lf, a.eps);
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const int row = wave * 8 + rr, s = q0 + row;
-            float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + lane * 4);
-            v = make_float4(v.x + x1[rr].x, v.y + x1[rr].y, v.z + x1[rr].z, v.w + x1[rr].w);
-            v = wave_layernorm256(v, lp, a.eps);
-            if (a.fin_w != nullptr) v = wave_layernorm256(v, lf, a.eps);
-            if (s >= a.q_rows) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s >= a.q_rows) v[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.out != nullptr && s < a.q_rows) {
                 const size_t orow = a.out_mode == 1 ? (size_t)s * a.B + b : base + s;
-                *reinterpret_cast<float4*>(a.out + orow * 256 + lane * 4) = v;
+                *reinterpret_cast<float4*>(a.out + orow * 256 + lane * 4) = v[rr];
             }
-            if (has_tail) rows_to_h16(Xh, ldq, row, lane, v);
+            if (has_tail) rows_to_h16(Xh, ldq, row, lane, v[rr]);
         }
     }
+    LAYER_DBG(9);
     if (!has_tail) return;
     __syncthreads();
     if (a.skip_w != nullptr) {   // x = W_skip . cat(x, skip rows) + b : two K = 256 halves, the second operand tile in R0
@@ -992,8 +1068,10 @@ __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) 
         }
         __syncthreads();
     }
+    LAYER_DBG(10);
     if (a.qkv_w != nullptr) {    // q | k | V^T of the next layer for these rows, into the other buffer set
-        tail_qkv_rows(Xh, reinterpret_cast<unsigned short*>(R0), a.qkv_w, a.qkv_b, a.qk_out, a.vt_out, b, q0, a.S, a.spv, ring_t);
+        tail_qkv_rows(Xh, reinterpret_cast<unsigned short*>(R0), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
+        LAYER_DBG(11);
         return;
     }
     if (a.proj_w != nullptr) {   // final projection to the feature width (decoder): the stack LN was applied above
@@ -1030,7 +1108,7 @@ struct ProHArgs {
     int mode, B, S, T, F, spv;
     const float* features; const uint4* emb_w; const float* emb_b; const float* token; const float* pe;
     float* x;
-    const uint4* qkv_w; const float* qkv_b; unsigned short* qk_out; unsigned short* vt_out;
+    const uint4* qkv_w; const float* qkv_b; unsigned short* q_out; uint4* kp_out; uint4* vp_out;
 };
 __global__ __launch_bounds__(256) void k_vae_pro_h(const ProHArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1073,7 +1151,7 @@ __global__ __launch_bounds__(256) void k_vae_pro_h(const ProHArgs a) {
         rows_to_h16(Xh, ldq, row, lane, v);
     }
     __syncthreads();
-    tail_qkv_rows(Xh, reinterpret_cast<unsigned short*>(Cs), a.qkv_w, a.qkv_b, a.qk_out, a.vt_out, b, q0, a.S, a.spv, ring_t);
+    tail_qkv_rows(Xh, reinterpret_cast<unsigned short*>(Cs), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
 }
 static int launch_pro_h(const ProHArgs& a, hipStream_t st) {
     if (a.mode == 1 && a.F > 256) return seeme_fail("vae_pro_h: nfeats > 256");
@@ -1099,7 +1177,7 @@ __global__ void k_bcast_rows_h(const float* __restrict__ src, float* __restrict_
     reinterpret_cast<float4*>(dst)[idx] = reinterpret_cast<const float4*>(src)[idx % per];
 }
 
-struct WsH { float *x, *y, *sk0, *sk1, *cvec; unsigned short *qk, *vt; int spv; };
+struct WsH { float *x, *y, *sk0, *sk1, *cvec; unsigned short *qk, *vt; int spv; uint4* kp[2]; };
 static WsH carve_h(void* ws, int B, int S) {
     const size_t R = (size_t)B * S;
     float* p = (float*)ws;
@@ -1111,6 +1189,9 @@ static WsH carve_h(void* ws, int B, int S) {
     w.vt = h;                                        // B*256*spv halves <= R*1024 halves
     p += R * 768;
     w.cvec = p;
+    p += (size_t)B * 256 * (SEEME_NLAYERS + 1) + 64;     // (vae_ws_floats) the two sets of fragment-packed keys of the one-kernel-per-layer path
+    w.kp[0] = reinterpret_cast<uint4*>(p);
+    w.kp[1] = reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p) + (size_t)B * ((S + 15) & ~15) * 256);
     return w;
 }
 
@@ -1208,25 +1289,21 @@ static int vae_decode_h16_unfused(const SeemeVaeWeights* w, const float* z, cons
 
 // ---------------------------------------------------------------------------------------------
 // One kernel per layer (k_layer_h); SEEME_VAE_FUSED=0 selects the three-kernels-per-layer sequence above.
-static int vae_fused_mode() {     // 0: three kernels per layer; 1: one kernel per layer; 2 (debug): one kernel per layer, tails as separate launches
+static bool vae_fused_enabled() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("SEEME_VAE_FUSED"); v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
-    return v;
+    if (v < 0) { const char* e = getenv("SEEME_VAE_FUSED"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
 }
-static bool vae_fused_enabled() { return vae_fused_mode() != 0; }
-struct KvSet { unsigned short* qk; unsigned short* vt; };
-
-static int qkv_first_h(hipStream_t st, const SeemeXfLayer& L, const SeemeXfLayerH& H, const float* cur, const KvSet& kv, int B, int S, int spv) {
-    LinearHArgs q{};
-    q.k.a.A = cur; q.k.a.lda = 256; q.k.a.K1 = 256; q.k.a.K = 256; q.k.a.bias = L.in_b; q.k.a.M = B * S; q.k.a.N = 768; q.k.a.eps = 1e-5f;
-    q.wp = (const uint4*)H.in_w; q.kstride = 8; q.ntiles = 48; q.qkv_mode = 1; q.qk = kv.qk; q.vt = kv.vt; q.S = S; q.spv = spv;
-    return ((reinterpret_cast<size_t>(cur) & 15) == 0) ? launch_qkv_h(q, st) : launch_linear_h(q, st);
+struct KvSet { unsigned short* q; uint4* kp; uint4* vp; };
+static void kv_sets(const WsH& ws, int B, KvSet (&kv)[2]) {
+    kv[0] = KvSet{ws.qk, ws.kp[0], reinterpret_cast<uint4*>(ws.vt)};
+    kv[1] = KvSet{reinterpret_cast<unsigned short*>(ws.y), ws.kp[1], reinterpret_cast<uint4*>(ws.vt + (size_t)B * 256 * ws.spv)};
 }
 
 static LayerHArgs layer_args(const SeemeXfLayer& L, const SeemeXfLayerH& H, const KvSet& in, const float* res, const int32_t* lengths,
                              int B, int S, int spv, int n_prefix, int q_rows, const float* cvec, int cvec_ld) {
     LayerHArgs a{};
-    a.qk = in.qk; a.vt = in.vt; a.res = res; a.wo = (const uint4*)H.out_w; a.bo = L.out_b; a.n1_w = L.n1_w; a.n1_b = L.n1_b;
+    a.q = in.q; a.kp = in.kp; a.vp = in.vp; a.res = res; a.wo = (const uint4*)H.out_w; a.bo = L.out_b; a.n1_w = L.n1_w; a.n1_b = L.n1_b;
     a.lengths = lengths; a.S = S; a.n_prefix = n_prefix; a.q_rows = q_rows; a.spv = spv; a.scale = 1.0f / 16.0f; a.eps = 1e-5f;
     a.w1 = (const uint4*)H.l1_w; a.b1 = L.l1_b; a.w2 = (const uint4*)H.l2_w; a.b2 = L.l2_b; a.B = B;
     if (cvec != nullptr) { a.cvec = cvec; a.cvec_ld = cvec_ld; a.lnc_w = L.n2_w; a.lnc_b = L.n2_b; a.n2_w = L.n3_w; a.n2_b = L.n3_b; }
@@ -1234,27 +1311,10 @@ static LayerHArgs layer_args(const SeemeXfLayer& L, const SeemeXfLayerH& H, cons
     return a;
 }
 static void tail_qkv(LayerHArgs& a, const SeemeXfLayer& Ln, const SeemeXfLayerH& Hn, const KvSet& out) {
-    a.qkv_w = (const uint4*)Hn.in_w; a.qkv_b = Ln.in_b; a.qk_out = out.qk; a.vt_out = out.vt;
+    a.qkv_w = (const uint4*)Hn.in_w; a.qkv_b = Ln.in_b; a.q_out = out.q; a.kp_out = out.kp; a.vp_out = out.vp;
 }
 static void tail_skip(LayerHArgs& a, const uint16_t* wp, const float* b, const float* src, float* xnext) {
     a.skip_w = (const uint4*)wp; a.skip_b = b; a.skip_src = src; a.xnext = xnext;
-}
-
-// debug mode 2: run the layer without its tails, then the tails as the stand-alone kernels (bisecting numerical differences)
-static int launch_layer_dbg(LayerHArgs a, hipStream_t st, float* tmp_out, const SeemeXfLayer* Ln, const SeemeXfLayerH* Hn) {
-    if (vae_fused_mode() != 2 || (a.skip_w == nullptr && a.qkv_w == nullptr)) return launch_layer_h(a, st);
-    LayerHArgs b = a;
-    b.skip_w = nullptr; b.qkv_w = nullptr;
-    float* x = a.out != nullptr ? a.out : tmp_out;
-    b.out = x;
-    int rc = launch_layer_h(b, st);
-    if (rc) return rc;
-    if (a.skip_w != nullptr) {
-        if ((rc = skip_lin_h(st, x, a.skip_src, (const uint16_t*)a.skip_w, a.skip_b, a.xnext, a.B * a.S))) return rc;
-        x = a.xnext;
-    }
-    KvSet kv{a.qk_out, a.vt_out};
-    return qkv_first_h(st, *Ln, *Hn, x, kv, a.B, a.S, a.spv);
 }
 
 int seeme_vae_encode_h16(const SeemeVaeWeights* w, const float* features, const int32_t* lengths, int B, int T, float* mu,
@@ -1264,38 +1324,28 @@ int seeme_vae_encode_h16(const SeemeVaeWeights* w, const float* features, const 
     WsH ws = carve_h(workspace, B, S);
     if (!vae_fused_enabled() || ws.spv > 2 * S) return vae_encode_h16_unfused(w, features, lengths, B, T, mu, workspace, st);
     const SeemeSkipStack& E = w->enc;
-    const KvSet kv[2] = {{ws.qk, ws.vt}, {reinterpret_cast<unsigned short*>(ws.y), ws.vt + (size_t)B * 256 * ws.spv}};
+    KvSet kv[2];
+    kv_sets(ws, B, kv);
     int rc;
-    if (vae_fused_mode() == 2) {
-        SEEME_HIP(hipMemsetAsync(ws.vt, 0, (size_t)B * 256 * ws.spv * 2 * 2, st));
-        hipLaunchKernelGGL(k_enc_tokens_h, dim3((B * 512 + 255) / 256), dim3(256), 0, st, w->token, w->pe_enc, ws.x, B, S);
-        if ((rc = seeme_check_launch("k_enc_tokens_h"))) return rc;
-        LinearHArgs ha{};
-        ha.k.a.A = features; ha.k.a.lda = F; ha.k.a.K1 = F; ha.k.a.K = F; ha.k.a.bias = w->emb_b; ha.k.a.res = w->pe_enc; ha.k.a.ldr = 256;
-        ha.k.a.Y = ws.x; ha.k.a.ldy = 256; ha.k.a.M = B * T; ha.k.a.N = 256; ha.k.a.eps = 1e-5f;
-        ha.k.seq_in = T; ha.k.in_stride = T; ha.k.out_stride = S; ha.k.out_off = 2; ha.k.res_mode = 1; ha.k.res_off = 2;
-        ha.wp = (const uint4*)H->emb_w; ha.kstride = ((F + 31) & ~31) >> 5; ha.ntiles = 16;
-        if ((rc = launch_linear_h(ha, st))) return rc;
-        if ((rc = qkv_first_h(st, E.layer[0], H->enc[0], ws.x, kv[0], B, S, ws.spv))) return rc;
-    } else {
+    {
         ProHArgs p{};
         p.mode = 1; p.B = B; p.S = S; p.T = T; p.F = F; p.spv = ws.spv; p.features = features; p.emb_w = (const uint4*)H->emb_w;
         p.emb_b = w->emb_b; p.token = w->token; p.pe = w->pe_enc; p.x = ws.x;
-        p.qkv_w = (const uint4*)H->enc[0].in_w; p.qkv_b = E.layer[0].in_b; p.qk_out = kv[0].qk; p.vt_out = kv[0].vt;
+        p.qkv_w = (const uint4*)H->enc[0].in_w; p.qkv_b = E.layer[0].in_b; p.q_out = kv[0].q; p.kp_out = kv[0].kp; p.vp_out = kv[0].vp;
         if ((rc = launch_pro_h(p, st))) return rc;
     }
     LayerHArgs a = layer_args(E.layer[0], H->enc[0], kv[0], ws.x, lengths, B, S, ws.spv, 2, S, nullptr, 0);
     a.out = ws.sk0; tail_qkv(a, E.layer[1], H->enc[1], kv[1]);
-    if ((rc = launch_layer_dbg(a, st, ws.x, &E.layer[1], &H->enc[1]))) return rc;
+    if ((rc = launch_layer_h(a, st))) return rc;
     a = layer_args(E.layer[1], H->enc[1], kv[1], ws.sk0, lengths, B, S, ws.spv, 2, S, nullptr, 0);
     a.out = ws.sk1; tail_qkv(a, E.layer[2], H->enc[2], kv[0]);
-    if ((rc = launch_layer_dbg(a, st, ws.x, &E.layer[2], &H->enc[2]))) return rc;
+    if ((rc = launch_layer_h(a, st))) return rc;
     a = layer_args(E.layer[2], H->enc[2], kv[0], ws.sk1, lengths, B, S, ws.spv, 2, S, nullptr, 0);
     tail_skip(a, H->enc_skip[0], E.skip_b[0], ws.sk1, ws.x); tail_qkv(a, E.layer[3], H->enc[3], kv[1]);
-    if ((rc = launch_layer_dbg(a, st, ws.x, &E.layer[3], &H->enc[3]))) return rc;
+    if ((rc = launch_layer_h(a, st))) return rc;
     a = layer_args(E.layer[3], H->enc[3], kv[1], ws.x, lengths, B, S, ws.spv, 2, S, nullptr, 0);
     tail_skip(a, H->enc_skip[1], E.skip_b[1], ws.sk0, ws.x); tail_qkv(a, E.layer[4], H->enc[4], kv[0]);
-    if ((rc = launch_layer_dbg(a, st, ws.x, &E.layer[4], &H->enc[4]))) return rc;
+    if ((rc = launch_layer_h(a, st))) return rc;
     a = layer_args(E.layer[4], H->enc[4], kv[0], ws.x, lengths, B, S, ws.spv, 2, 2, nullptr, 0);
     a.out = mu; a.out_mode = 1; a.fin_w = E.norm_w; a.fin_b = E.norm_b;
     return launch_layer_h(a, st);
@@ -1309,34 +1359,29 @@ int seeme_vae_decode_h16(const SeemeVaeWeights* w, const float* z, const int32_t
     ws.spv = (S + 31) & ~31;
     if (!vae_fused_enabled() || ws.spv > 2 * S || F > 256) return vae_decode_h16_unfused(w, z, lengths, B, T, feats, workspace, st);
     const SeemeSkipStack& Dk = w->dec;
-    const KvSet kv[2] = {{ws.qk, ws.vt}, {reinterpret_cast<unsigned short*>(ws.y), ws.vt + (size_t)B * 256 * ws.spv}};
+    KvSet kv[2];
+    kv_sets(ws, B, kv);
     int rc;
     const int CL = SEEME_NLAYERS * 256;
     if ((rc = lin_h(st, z, 256, H->ca_fold_w, 256, CL, w->ca_fold_b, ws.cvec, CL, B))) return rc;
-    if (vae_fused_mode() == 2) {
-        SEEME_HIP(hipMemsetAsync(ws.vt, 0, (size_t)B * 256 * ws.spv * 2 * 2, st));
-        const size_t n4 = (size_t)B * S * 64;
-        hipLaunchKernelGGL(k_bcast_rows_h, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w->pe_dec, ws.x, B, S);
-        if ((rc = seeme_check_launch("k_bcast_rows_h"))) return rc;
-        if ((rc = qkv_first_h(st, Dk.layer[0], H->dec[0], ws.x, kv[0], B, S, ws.spv))) return rc;
-    } else {
+    {
         ProHArgs p{};
         p.mode = 2; p.B = B; p.S = S; p.T = T; p.F = F; p.spv = ws.spv; p.pe = w->pe_dec; p.x = ws.x;
-        p.qkv_w = (const uint4*)H->dec[0].in_w; p.qkv_b = Dk.layer[0].in_b; p.qk_out = kv[0].qk; p.vt_out = kv[0].vt;
+        p.qkv_w = (const uint4*)H->dec[0].in_w; p.qkv_b = Dk.layer[0].in_b; p.q_out = kv[0].q; p.kp_out = kv[0].kp; p.vp_out = kv[0].vp;
         if ((rc = launch_pro_h(p, st))) return rc;
     }
     LayerHArgs a = layer_args(Dk.layer[0], H->dec[0], kv[0], ws.x, lengths, B, S, ws.spv, 0, S, ws.cvec + 0 * 256, CL);
     a.out = ws.sk0; tail_qkv(a, Dk.layer[1], H->dec[1], kv[1]);
-    if ((rc = launch_layer_dbg(a, st, ws.x, &Dk.layer[1], &H->dec[1]))) return rc;
+    if ((rc = launch_layer_h(a, st))) return rc;
     a = layer_args(Dk.layer[1], H->dec[1], kv[1], ws.sk0, lengths, B, S, ws.spv, 0, S, ws.cvec + 1 * 256, CL);
     a.out = ws.sk1; tail_qkv(a, Dk.layer[2], H->dec[2], kv[0]);
-    if ((rc = launch_layer_dbg(a, st, ws.x, &Dk.layer[2], &H->dec[2]))) return rc;
+    if ((rc = launch_layer_h(a, st))) return rc;
     a = layer_args(Dk.layer[2], H->dec[2], kv[0], ws.sk1, lengths, B, S, ws.spv, 0, S, ws.cvec + 2 * 256, CL);
     tail_skip(a, H->dec_skip[0], Dk.skip_b[0], ws.sk1, ws.x); tail_qkv(a, Dk.layer[3], H->dec[3], kv[1]);
-    if ((rc = launch_layer_dbg(a, st, ws.x, &Dk.layer[3], &H->dec[3]))) return rc;
+    if ((rc = launch_layer_h(a, st))) return rc;
     a = layer_args(Dk.layer[3], H->dec[3], kv[1], ws.x, lengths, B, S, ws.spv, 0, S, ws.cvec + 3 * 256, CL);
     tail_skip(a, H->dec_skip[1], Dk.skip_b[1], ws.sk0, ws.x); tail_qkv(a, Dk.layer[4], H->dec[4], kv[0]);
-    if ((rc = launch_layer_dbg(a, st, ws.x, &Dk.layer[4], &H->dec[4]))) return rc;
+    if ((rc = launch_layer_h(a, st))) return rc;
     a = layer_args(Dk.layer[4], H->dec[4], kv[0], ws.x, lengths, B, S, ws.spv, 0, S, ws.cvec + 4 * 256, CL);
     a.fin_w = Dk.norm_w; a.fin_b = Dk.norm_b; a.proj_w = (const uint4*)H->fin_w; a.proj_b = w->fin_b; a.feats = feats; a.F = F;
     return launch_layer_h(a, st);

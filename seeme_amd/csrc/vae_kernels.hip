@@ -478,7 +478,8 @@ struct VaeWs {
 };
 static size_t vae_ws_floats(int B, int S) {
     const size_t R = (size_t)B * S;
-    return R * 256 * 4 + R * 768 + (size_t)B * 256 * (SEEME_NLAYERS + 1) + 64;
+    // + the fp16 path's two sets of fragment-packed keys (vae_h16.hip): 2 x B x ceil16(S) x 256 halves
+    return R * 256 * 4 + R * 768 + (size_t)B * 256 * (SEEME_NLAYERS + 1) + 64 + (size_t)B * ((S + 15) & ~15) * 256;
 }
 extern "C" size_t seeme_vae_workspace_bytes(int B, int T) { return vae_ws_floats(B, T + 2) * sizeof(float); }
 
