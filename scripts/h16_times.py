@@ -28,3 +28,5 @@ if k == 5:
     t2 = np.array(buf[16:21], dtype=np.float64)
     print("  LN1 phase detail (cycles since the phase's barrier):", [int(x - t[5]) for x in t2],
           "= loads issued, tile + residual in registers, LN of 8 rows done, 2nd LN done, operand rows stored")
+    t3 = np.array(buf[23:26], dtype=np.float64)
+    print("  out_proj phase detail (cycles since the phase's barrier):", [int(x - t[4]) for x in t3], "= GEMM done, tile stored, FFN requests issued; the rest is the barrier")

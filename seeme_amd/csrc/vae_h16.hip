@@ -91,9 +91,11 @@ __device__ __forceinline__ void tile_gemm_h16(const unsigned short* __restrict__
                 for (int nt = 0; nt < NTL; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, ab[u & 1][mt]), __builtin_bit_cast(h16x8, br[u][nt]), acc[mt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef H16_DBG_NOREFILL       // timing-only ablation: the MFMAs keep reading the primed k-blocks (wrong results)
             const int kn = kb + PF < K32 ? kb + PF : K32 - 1;
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt) br[u][nt] = loadb(nt, kn);
+#endif
         }
     }
 #pragma unroll
@@ -812,50 +814,53 @@ __device__ __forceinline__ void rows_to_h16(unsigned short* Xh, int ldh, int row
 // (row-major K rows / V^T rows made every wave-load touch 16 rows x 64 B; the V^T rows were written two bytes at a time).
 // Value granules of keys in [S, spv) are written as zeros by the tiles that cover them (P = 0 there, but 0 x garbage is not);
 // key rows in [S, 16 NT16) stay unwritten: their score columns are masked by a select.
+template <int WAVES>
 __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned short* Oh, const uint4* __restrict__ qkv_w,
                                               const float* __restrict__ qkv_b, unsigned short* __restrict__ q_out,
                                               uint4* __restrict__ kp_out, uint4* __restrict__ vp_out, int b, int q0, int S, int spv,
-                                              BRing<4, H16_PF>& ring_t) {
+                                              BRing<16 / WAVES, H16_PF>& ring_t) {
+    constexpr int ROWS = 8 * WAVES, MTL = ROWS / 16, NTL = 16 / WAVES, CW = 256 / WAVES, NT = 64 * WAVES;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int ldq = 256 + HPAD;
     const size_t base = (size_t)b * S;
     const int NT16 = (S + 15) >> 4, KB = spv >> 5;
     for (int y = 0; y < 3; ++y) {
-        f32x4 acc[2][4];
+        f32x4 acc[MTL][NTL];
         acc_zero(acc);
-        const BiasRegs<4> bias = bias_load<4>(qkv_b, y * 256 + wave * 64, 768);
-        gemm_packed<2, 4>(Xh, ldq, qkv_w, 8, y * 16 + wave * 4, 48, 8, acc, ring_t);
-        if (y < 2) prime_packed(ring_t, qkv_w, 8, (y + 1) * 16 + wave * 4, 48, 8);
+        const BiasRegs<NTL> bias = bias_load<NTL>(qkv_b, y * 256 + wave * CW, 768);
+        gemm_packed<MTL, NTL>(Xh, ldq, qkv_w, 8, y * 16 + wave * NTL, 48, 8, acc, ring_t);
+        if (y < 2) prime_packed(ring_t, qkv_w, 8, (y + 1) * 16 + wave * NTL, 48, 8);
         __syncthreads();                    // the previous part's stores have read the output tile
-        acc_store_h16<2, 4>(acc, Oh, ldq, wave * 64, bias, SEEME_ACT_NONE);
+        acc_store_h16<MTL, NTL>(acc, Oh, ldq, wave * CW, bias, SEEME_ACT_NONE);
         __syncthreads();
         if (y == 0) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int idx = tid + it * 256, row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
+                const int idx = tid + it * NT, row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
                 if (s < S) *reinterpret_cast<uint4*>(q_out + (base + s) * 256 + c8) = *reinterpret_cast<const uint4*>(Oh + row * ldq + c8);
             }
         } else if (y == 1) {
             uint4* kb_out = kp_out + ((size_t)b * NT16 + (q0 >> 4)) * 512;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int idx = tid + it * 256, r = idx & 15, kq = (idx >> 4) & 3, kb = (idx >> 6) & 7, half = idx >> 9, row = half * 16 + r;
+                const int idx = tid + it * NT, r = idx & 15, kq = (idx >> 4) & 3, kb = (idx >> 6) & 7, half = idx >> 9, row = half * 16 + r;
                 if (q0 + row < S) kb_out[(half * 8 + kb) * 64 + kq * 16 + r] = *reinterpret_cast<const uint4*>(Oh + row * ldq + kb * 32 + kq * 8);
             }
         } else {
-            uint4* vb_out = vp_out + (size_t)b * 16 * KB * 64 + (size_t)(q0 >> 5) * 64;
+            uint4* vb_out = vp_out + (size_t)b * 16 * KB * 64;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int idx = tid + it * 256, r = idx & 15, g = (idx >> 4) & 3, nt = idx >> 6;
-                const unsigned short* src = Oh + (8 * g) * ldq + nt * 16 + r;
+                const int idx = tid + it * NT, r = idx & 15, g = (idx >> 4) & 3, nt = (idx >> 6) & 15, kh = idx >> 10;   // kh: 32-key block inside the tile
+                const int row0 = 32 * kh + 8 * g, kb = (q0 >> 5) + kh;
+                const unsigned short* src = Oh + row0 * ldq + nt * 16 + r;
                 unsigned w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int s0 = q0 + 8 * g + 2 * j;
+                    const int s0 = q0 + row0 + 2 * j;
                     const unsigned lo = s0 < S ? src[(2 * j) * ldq] : 0u, hi = s0 + 1 < S ? src[(2 * j + 1) * ldq] : 0u;
                     w[j] = lo | (hi << 16);
                 }
-                vb_out[(size_t)nt * KB * 64 + g * 16 + r] = make_uint4(w[0], w[1], w[2], w[3]);
+                if (kb < KB) vb_out[((size_t)nt * KB + kb) * 64 + g * 16 + r] = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
     }
@@ -863,12 +868,14 @@ __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned
 
 // debug stamps of a layer that has the next layer's QKV as its tail (the last launch of those in a pass is what is read back)
 #define LAYER_DBG(i) do { if (a.qkv_w != nullptr) H16_DBG(5, i); } while (0)
-__global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) {
+template <int WAVES>      // 4: 32 query rows per workgroup (256 threads, LAYER_WPE per CU); 8: 64 rows (512 threads, one per CU) -- half the L2 -> L1 bytes per row
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_layer_h(const LayerHArgs a) {
+    constexpr int ROWS = 8 * WAVES, MTL = ROWS / 16, NTL = 16 / WAVES, CW = 256 / WAVES, N1 = 8 / WAVES, NT = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
     const int ldp = a.Sp + LDS_PAD, ldq = 256 + HPAD, ldph = 2 * ldp, ldc = 256 + LDS_PAD;
     float* R0 = smem;
-    unsigned short* R1 = reinterpret_cast<unsigned short*>(R0 + TILE_M * ldp);
+    unsigned short* R1 = reinterpret_cast<unsigned short*>(R0 + ROWS * ldp);
     float* Ps = R0;
     unsigned short* Ph = reinterpret_cast<unsigned short*>(R0);
     unsigned short* Qh = R1;
@@ -878,24 +885,24 @@ __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) 
         b = rr + 8 * (q / (int)gridDim.x);
         qt = q % (int)gridDim.x;
     }
-    const int q0 = qt * TILE_M;
+    const int q0 = qt * ROWS;
     const size_t base = (size_t)b * a.S;
     const int n_valid_keys = min(a.S, a.n_prefix + a.lengths[b]);
-    const BiasRegs<4> bias_o = bias_load<4>(a.bo, wave * 64, 256);
-    BRing<4, ATT_PF> ring_o;
-    prime_packed(ring_o, a.wo, 8, wave * 4, 16, 8);
+    const BiasRegs<NTL> bias_o = bias_load<NTL>(a.bo, wave * CW, 256);
+    BRing<NTL, ATT_PF> ring_o;
+    prime_packed(ring_o, a.wo, 8, wave * NTL, 16, 8);
     LAYER_DBG(0);
     {   // Q tile
         uint4 qv[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int idx = tid + it * 256, row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
+            const int idx = tid + it * NT, row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
             qv[it] = *reinterpret_cast<const uint4*>(a.q + (base + (s < a.q_rows ? s : 0)) * 256 + c8);
             if (s >= a.q_rows) qv[it] = make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int idx = tid + it * 256, row = idx >> 5, c8 = (idx & 31) * 8;
+            const int idx = tid + it * NT, row = idx >> 5, c8 = (idx & 31) * 8;
             *reinterpret_cast<uint4*>(Qh + row * ldq + c8) = qv[it];
         }
     }
@@ -904,16 +911,16 @@ __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) 
     const int NT16 = (a.S + 15) >> 4;
     const uint4* Kp = a.kp + (size_t)b * NT16 * 512;
     for (int c0 = 0; c0 < a.Sp; c0 += CH_N) {
-        const int n0 = c0 + wave * 64;
-        f32x4 acc[2][4];
+        const int n0 = c0 + wave * CW;
+        f32x4 acc[MTL][NTL];
         acc_zero(acc);
-        if (n0 < a.S) gemm_packed<2, 4, LAYER_KV_PF>(Qh, ldq, Kp, 8, n0 >> 4, NT16, 8, acc);
+        if (n0 < a.S) gemm_packed<MTL, NTL, LAYER_KV_PF>(Qh, ldq, Kp, 8, n0 >> 4, NT16, 8, acc);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NTL; ++nt) {
             const int c = n0 + nt * 16 + r;
             const bool ok = c < n_valid_keys;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) Ps[(mt * 16 + 4 * kq + i) * ldp + c] = ok ? acc[mt][nt][i] * a.scale : -INFINITY;
         }
@@ -925,28 +932,34 @@ __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) 
     __syncthreads();
     LAYER_DBG(3);
     {   // O = P V
-        f32x4 acc[2][4];
+        f32x4 acc[MTL][NTL];
         acc_zero(acc);
         const int K32 = (n_valid_keys + 31) >> 5;
-        gemm_packed<2, 4, LAYER_KV_PF>(Ph, ldph, a.vp + (size_t)b * 16 * (a.spv >> 5) * 64, a.spv >> 5, wave * 4, 16, K32, acc);
-        acc_store_h16<2, 4>(acc, Qh, ldq, wave * 64, nullptr, SEEME_ACT_NONE);
+        gemm_packed<MTL, NTL, LAYER_KV_PF>(Ph, ldph, a.vp + (size_t)b * 16 * (a.spv >> 5) * 64, a.spv >> 5, wave * NTL, 16, K32, acc);
+        acc_store_h16<MTL, NTL>(acc, Qh, ldq, wave * CW, nullptr, SEEME_ACT_NONE);
     }
     __syncthreads();
     LAYER_DBG(4);
     float* Cs = R0;
     {
-        f32x4 acc[2][4];
+        f32x4 acc[MTL][NTL];
         acc_zero(acc);
-        gemm_packed<2, 4, ATT_PF>(Qh, ldq, a.wo, 8, wave * 4, 16, 8, acc, ring_o);
-        acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, bias_o, SEEME_ACT_NONE);
+        gemm_packed<MTL, NTL, ATT_PF>(Qh, ldq, a.wo, 8, wave * NTL, 16, 8, acc, ring_o);
+#ifdef H16_DBG_TIMES
+        asm volatile("" : "+v"(acc[0][0][0]), "+v"(acc[MTL - 1][NTL - 1][3]));
+        LAYER_DBG(23);
+#endif
+        acc_store_lds<MTL, NTL>(acc, Cs, ldc, wave * CW, bias_o, SEEME_ACT_NONE);
     }
+    LAYER_DBG(24);
     // FFN weights requested now: their cold miss overlaps LN1
-    const BiasRegs<2> bias1 = bias_load<2>(a.b1, wave * 32, 128);
-    const BiasRegs<4> bias2 = bias_load<4>(a.b2, wave * 64, 256);
-    BRing<2, FFN_PF> ring1;
-    BRing<4, H16_PF> ring2;
-    prime_packed(ring1, a.w1, 8, wave * 2, 8, 8);
-    prime_packed(ring2, a.w2, 4, wave * 4, 16, 4);
+    const BiasRegs<N1> bias1 = bias_load<N1>(a.b1, wave * (128 / WAVES), 128);
+    const BiasRegs<NTL> bias2 = bias_load<NTL>(a.b2, wave * CW, 256);
+    BRing<N1, FFN_PF> ring1;
+    BRing<NTL, H16_PF> ring2;
+    prime_packed(ring1, a.w1, 8, wave * N1, 8, 8);
+    prime_packed(ring2, a.w2, 4, wave * NTL, 16, 4);
+    LAYER_DBG(25);
     __syncthreads();
     LAYER_DBG(5);
     unsigned short* Xh = R1;
@@ -989,26 +1002,26 @@ __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) 
     unsigned short* Hh = R1;                     // hidden [32][144] overwrites the operand once every wave has read it
     const int ldhh = 128 + HPAD;
     {
-        f32x4 acc1[2][2];
+        f32x4 acc1[MTL][N1];
         acc_zero(acc1);
-        gemm_packed<2, 2, FFN_PF>(Xh, ldq, a.w1, 8, wave * 2, 8, 8, acc1, ring1);
+        gemm_packed<MTL, N1, FFN_PF>(Xh, ldq, a.w1, 8, wave * N1, 8, 8, acc1, ring1);
         __syncthreads();
-        acc_store_h16<2, 2>(acc1, Hh, ldhh, wave * 32, bias1, SEEME_ACT_GELU);
+        acc_store_h16<MTL, N1>(acc1, Hh, ldhh, wave * (128 / WAVES), bias1, SEEME_ACT_GELU);
     }
     __syncthreads();
     LAYER_DBG(7);
     {
-        f32x4 acc2[2][4];
+        f32x4 acc2[MTL][NTL];
         acc_zero(acc2);
-        gemm_packed<2, 4>(Hh, ldhh, a.w2, 4, wave * 4, 16, 4, acc2, ring2);
-        acc_store_lds<2, 4>(acc2, Cs, ldc, wave * 64, bias2, SEEME_ACT_NONE);
+        gemm_packed<MTL, NTL>(Hh, ldhh, a.w2, 4, wave * NTL, 16, 4, acc2, ring2);
+        acc_store_lds<MTL, NTL>(acc2, Cs, ldc, wave * CW, bias2, SEEME_ACT_NONE);
     }
     // tail weights requested now
     const bool has_tail = a.skip_w != nullptr || a.qkv_w != nullptr || a.proj_w != nullptr;
-    BRing<4, H16_PF> ring_t;
-    if (a.skip_w != nullptr) prime_packed(ring_t, a.skip_w, 16, wave * 4, 16, 8);
-    else if (a.qkv_w != nullptr) prime_packed(ring_t, a.qkv_w, 8, wave * 4, 48, 8);
-    else if (a.proj_w != nullptr) prime_packed(ring_t, a.proj_w, 8, wave * 4, (a.F + 15) >> 4, 8);
+    BRing<NTL, H16_PF> ring_t;
+    if (a.skip_w != nullptr) prime_packed(ring_t, a.skip_w, 16, wave * NTL, 16, 8);
+    else if (a.qkv_w != nullptr) prime_packed(ring_t, a.qkv_w, 8, wave * NTL, 48, 8);
+    else if (a.proj_w != nullptr) prime_packed(ring_t, a.proj_w, 8, wave * NTL, (a.F + 15) >> 4, 8);
     __syncthreads();
     LAYER_DBG(8);
     {   // +residual, LN [, stack LN]; layer output rows
@@ -1048,15 +1061,15 @@ __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) 
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) rows_to_h16(Sh, ldq, wave * 8 + rr, lane, sv[rr]);
         }
-        const BiasRegs<4> bias_s = bias_load<4>(a.skip_b, wave * 64, 256);
+        const BiasRegs<NTL> bias_s = bias_load<NTL>(a.skip_b, wave * CW, 256);
         __syncthreads();
-        f32x4 acc[2][4];
+        f32x4 acc[MTL][NTL];
         acc_zero(acc);
-        gemm_packed<2, 4>(Xh, ldq, a.skip_w, 16, wave * 4, 16, 8, acc, ring_t);
-        gemm_packed<2, 4>(Sh, ldq, a.skip_w + 8 * 64, 16, wave * 4, 16, 8, acc);
-        if (a.qkv_w != nullptr) prime_packed(ring_t, a.qkv_w, 8, wave * 4, 48, 8);
+        gemm_packed<MTL, NTL>(Xh, ldq, a.skip_w, 16, wave * NTL, 16, 8, acc, ring_t);
+        gemm_packed<MTL, NTL>(Sh, ldq, a.skip_w + 8 * 64, 16, wave * NTL, 16, 8, acc);
+        if (a.qkv_w != nullptr) prime_packed(ring_t, a.qkv_w, 8, wave * NTL, 48, 8);
         __syncthreads();
-        acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, bias_s, SEEME_ACT_NONE);
+        acc_store_lds<MTL, NTL>(acc, Cs, ldc, wave * CW, bias_s, SEEME_ACT_NONE);
         __syncthreads();
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
@@ -1070,34 +1083,47 @@ __global__ __launch_bounds__(256, LAYER_WPE) void k_layer_h(const LayerHArgs a) 
     }
     LAYER_DBG(10);
     if (a.qkv_w != nullptr) {    // q | k | V^T of the next layer for these rows, into the other buffer set
-        tail_qkv_rows(Xh, reinterpret_cast<unsigned short*>(R0), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
+        tail_qkv_rows<WAVES>(Xh, reinterpret_cast<unsigned short*>(R0), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
         LAYER_DBG(11);
         return;
     }
     if (a.proj_w != nullptr) {   // final projection to the feature width (decoder): the stack LN was applied above
         const int ntiles = (a.F + 15) >> 4;
-        const BiasRegs<4> bias = bias_load<4>(a.proj_b, wave * 64, a.F);
-        f32x4 acc[2][4];
+        const BiasRegs<NTL> bias = bias_load<NTL>(a.proj_b, wave * CW, a.F);
+        f32x4 acc[MTL][NTL];
         acc_zero(acc);
-        if (wave * 4 < ntiles) gemm_packed<2, 4>(Xh, ldq, a.proj_w, 8, wave * 4, ntiles, 8, acc, ring_t);
-        acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, bias, SEEME_ACT_NONE);
+        if (wave * NTL < ntiles) gemm_packed<MTL, NTL>(Xh, ldq, a.proj_w, 8, wave * NTL, ntiles, 8, acc, ring_t);
+        acc_store_lds<MTL, NTL>(acc, Cs, ldc, wave * CW, bias, SEEME_ACT_NONE);
         __syncthreads();
-        for (int idx = tid; idx < TILE_M * 256; idx += 256) {
+        for (int idx = tid; idx < ROWS * 256; idx += NT) {
             const int row = idx >> 8, c = idx & 255, s = q0 + row;
             if (s < a.S && c < a.F) a.feats[(base + s) * a.F + c] = Cs[row * ldc + c];
         }
     }
 }
 
+// 32 query rows per workgroup by default.  The 64-row instantiation (SEEME_LAYER_ROWS=64; Sp <= 256 only: 102 KB of LDS) pulls
+// half the weight / K / V bytes per row from L2 and produces bit-identical results, and measures 1-2 % SLOWER at B = 256 / 512
+// (DESIGN.md section 5.2): L2 -> L1 bytes are not what bounds these tiles.
+static int layer_rows(const LayerHArgs& a) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("SEEME_LAYER_ROWS"); forced = e ? atoi(e) : 0; }
+    return (forced == 64 && a.Sp <= 256 && a.q_rows > 32) ? 64 : 32;
+}
+template <int WAVES>
+static int launch_layer_w(const LayerHArgs& a, hipStream_t st) {
+    constexpr int ROWS = 8 * WAVES;
+    const size_t lds = (size_t)ROWS * (a.Sp + LDS_PAD) * 4 + (size_t)ROWS * (256 + HPAD) * 2;
+    dim3 grid((a.q_rows + ROWS - 1) / ROWS, a.B);
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_layer_h<WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_layer_h<WAVES>, grid, dim3(64 * WAVES), lds, st, a);
+    return seeme_check_launch("k_layer_h");
+}
 static int launch_layer_h(const LayerHArgs& a_in, hipStream_t st) {
     LayerHArgs a = a_in;
     if (a.S <= 0 || a.S > 512) return seeme_fail("layer_h: S must be in 1..512");
     a.Sp = (a.S + CH_N - 1) / CH_N * CH_N;
-    const size_t lds = (size_t)TILE_M * (a.Sp + LDS_PAD) * 4 + (size_t)TILE_M * (256 + HPAD) * 2;
-    dim3 grid((a.q_rows + TILE_M - 1) / TILE_M, a.B);
-    SEEME_HIP(hipFuncSetAttribute((const void*)k_layer_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_layer_h, grid, dim3(256), lds, st, a);
-    return seeme_check_launch("k_layer_h");
+    return layer_rows(a) == 64 ? launch_layer_w<8>(a, st) : launch_layer_w<4>(a, st);
 }
 
 
@@ -1151,7 +1177,7 @@ __global__ __launch_bounds__(256) void k_vae_pro_h(const ProHArgs a) {
         rows_to_h16(Xh, ldq, row, lane, v);
     }
     __syncthreads();
-    tail_qkv_rows(Xh, reinterpret_cast<unsigned short*>(Cs), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
+    tail_qkv_rows<4>(Xh, reinterpret_cast<unsigned short*>(Cs), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
 }
 static int launch_pro_h(const ProHArgs& a, hipStream_t st) {
     if (a.mode == 1 && a.F > 256) return seeme_fail("vae_pro_h: nfeats > 256");
