@@ -533,6 +533,7 @@ struct DenKArgs {
                                // device pointer the compiler issues vector loads, whose waits drain the weight ring)
     int nhead;
     SeemeSampleArgs s;
+    int xcds, chains;          // workgroups are dealt to the 8 XCDs round-robin; xcds < 8 packs the `chains` working ones onto the first xcds
 };
 
 // Per-layer small operands (biases / LayerNorm params, the time token's K|V and AdaLN rows, the condition
@@ -600,7 +601,13 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_sample(const DenKArgs ka) {
     const DenLayout* __restrict__ lay = &ka.lay;
     const SeemeSampleArgs& A = ka.s;
     const int tid0 = threadIdx.x;
-    const int b = blockIdx.x, N = A.N, H = ka.nhead;
+    int b = blockIdx.x;
+    if (ka.xcds < 8) {         // fewer XCDs: fewer L2s that each pull the whole weight image from the Infinity Cache every step
+        const int x = blockIdx.x & 7;
+        b = (blockIdx.x >> 3) * ka.xcds + x;
+        if (x >= ka.xcds || b >= ka.chains) return;
+    }
+    const int N = A.N, H = ka.nhead;
     const int seg = 64 / H;                      // lanes per attention head
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int lane = tid0 & 63;
@@ -980,7 +987,17 @@ static int launch_den(const DenKArgs& ka, hipStream_t st) {
     const size_t lds = den_lds_bytes(MS, ka.s.N, WT::MFMA);
     if (lds > 160 * 1024) return seeme_fail("denoiser_sample: LDS budget exceeded");
     SEEME_HIP(hipFuncSetAttribute((const void*)k_den_sample<WT, MS, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_den_sample<WT, MS, V>), dim3(chains), dim3(DEN_THREADS), lds, st, ka);
+    // Workgroups go to the 8 XCDs round-robin, and every XCD's L2 (4 MB) pulls the whole weight image (9 MB at 16 bit) from the
+    // Infinity Cache once per step whether 4 or 16 of its CUs consume it.  ~16 chains per XCD measured best (B=32: 2 XCDs 4.64 ms,
+    // 4: 4.67, 8: 4.74, 1: 4.86 -- 32 CUs on one L2 run into its bandwidth); SEEME_DEN_XCDS=1..8 forces a count.
+    static int want = -1;
+    if (want < 0) { const char* e = getenv("SEEME_DEN_XCDS"); want = e ? atoi(e) : 0; if (want < 0 || want > 8) want = 0; }
+    DenKArgs k2 = ka;
+    k2.chains = chains;
+    k2.xcds = want ? want : (chains + 15) / 16;
+    if (k2.xcds > 8 || chains > 32 * k2.xcds) k2.xcds = 8;      // one workgroup per CU, 32 CUs per XCD
+    const int grid = k2.xcds < 8 ? (chains + k2.xcds - 1) / k2.xcds * 8 : chains;
+    hipLaunchKernelGGL((k_den_sample<WT, MS, V>), dim3(grid), dim3(DEN_THREADS), lds, st, k2);
     return seeme_check_launch("k_den_sample");
 }
 template <typename WT, int MS>

@@ -104,7 +104,7 @@ struct DenBwdArgs {
     const void* wb; int wb_bytes;      // transposed image
     DenLayoutB lb;
     const float* vp; DenLayout lay;    // vector params (LayerNorm weights) and their offsets
-    int B, N;
+    int B, N, xcds;                    // xcds < 8: the B working workgroups sit on the first xcds XCDs (see launch_den)
     const float* save;                 // [B, DT_TOTAL] from the forward
     const unsigned char* drop;         // [B, DM_TOTAL] dropout keep-masks of the forward, or NULL
     float drop_scale;
@@ -162,7 +162,13 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_bwd(const DenBwdArgs a) {
     const __amdgpu_buffer_rsrc_t wb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wb), 0, a.wb_bytes, 0x00020000);
     const int tid = threadIdx.x, lane = tid & 63;
     const bool w0 = (tid >> 6) == 0;                            // every wave runs the epilogue math; wave 0 writes
-    const int b = blockIdx.x, N = a.N;
+    int b = blockIdx.x;
+    if (a.xcds < 8) {
+        const int x = blockIdx.x & 7;
+        b = (blockIdx.x >> 3) * a.xcds + x;
+        if (x >= a.xcds || b >= a.B) return;
+    }
+    const int N = a.N;
     const float* __restrict__ sv0 = a.save + (size_t)b * DT_TOTAL;
     float* __restrict__ go0 = a.gout + (size_t)b * DB_TOTAL;
     const float* __restrict__ tt = a.ttab + (size_t)a.trow[b] * SEEME_TROW;
@@ -434,7 +440,12 @@ extern "C" int seeme_denoiser_backward_drop(const SeemeDenoiserWeights* w, const
     a.B = B; a.N = N; a.save = save; a.ctab = ctab; a.ttab = ttab; a.trow = trow; a.dout = dout;
     a.drop = drop; a.drop_scale = drop_scale;
     a.gout = gout; a.dctab = dctab; a.dttab = dttab;
-    hipLaunchKernelGGL(k_den_bwd, dim3(B), dim3(DEN_THREADS), 0, (hipStream_t)stream, a);
+    static int want = -1;
+    if (want < 0) { const char* e = getenv("SEEME_DEN_XCDS"); want = e ? atoi(e) : 0; if (want < 0 || want > 8) want = 0; }
+    a.xcds = want ? want : (B + 15) / 16;
+    if (a.xcds > 8 || B > 32 * a.xcds) a.xcds = 8;
+    const int grid = a.xcds < 8 ? (B + a.xcds - 1) / a.xcds * 8 : B;
+    hipLaunchKernelGGL(k_den_bwd, dim3(grid), dim3(DEN_THREADS), 0, (hipStream_t)stream, a);
     return seeme_check_launch("k_den_bwd");
 }
 
