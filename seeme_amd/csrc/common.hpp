@@ -286,22 +286,36 @@ __device__ __forceinline__ float wave_sum8(const float (&s)[8]) {
     w += dpp_f(w, 2);
     return w;
 }
-__device__ __forceinline__ float lane8(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 8 * j)); }
-__device__ __forceinline__ void wave_layernorm256_x8(float4 (&v)[8], const LnParams& p, float eps) {
-    float s[8];
+// RW rows per wave (8 or 4): lane l ends up with the total of row l / (64 / RW).  Both forms add a row's 64 partial sums in the
+// same pairing order (l ^ 32, l ^ 16, l ^ 8, quads, half-rows), so a row's result does not depend on how many rows its wave owns.
+template <int RW> __device__ __forceinline__ float wave_sum_rows(const float (&s)[RW]);
+template <> __device__ __forceinline__ float wave_sum_rows<8>(const float (&s)[8]) { return wave_sum8(s); }
+template <> __device__ __forceinline__ float wave_sum_rows<4>(const float (&s)[4]) {
+    const float t0 = swap_add32(s[0], s[2]), t1 = swap_add32(s[1], s[3]);
+    float w = swap_add16(t0, t1);
+    w += dpp_f(w, 3);
+    w += dpp_f(w, 0);
+    w += dpp_f(w, 1);
+    w += dpp_f(w, 2);
+    return w;
+}
+template <int RW> __device__ __forceinline__ float row_total(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (64 / RW) * j)); }
+template <int RW>
+__device__ __forceinline__ void wave_layernorm256_rows(float4 (&v)[RW], const LnParams& p, float eps) {
+    float s[RW];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = (v[j].x + v[j].y) + (v[j].z + v[j].w);
-    const float mean = wave_sum8(s) * (1.f / 256.f);
+    for (int j = 0; j < RW; ++j) s[j] = (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const float mean = wave_sum_rows<RW>(s) * (1.f / 256.f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float m = lane8(mean, j);
+    for (int j = 0; j < RW; ++j) {
+        const float m = row_total<RW>(mean, j);
         v[j] = make_float4(v[j].x - m, v[j].y - m, v[j].z - m, v[j].w - m);
         s[j] = (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
     }
-    const float rsl = 1.f / sqrtf(wave_sum8(s) * (1.f / 256.f) + eps);
+    const float rsl = 1.f / sqrtf(wave_sum_rows<RW>(s) * (1.f / 256.f) + eps);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float rs = lane8(rsl, j);
+    for (int j = 0; j < RW; ++j) {
+        const float rs = row_total<RW>(rsl, j);
         v[j] = make_float4(v[j].x * rs * p.w.x + p.b.x, v[j].y * rs * p.w.y + p.b.y, v[j].z * rs * p.w.z + p.b.z, v[j].w * rs * p.w.w + p.b.w);
     }
 }

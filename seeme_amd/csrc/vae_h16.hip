@@ -43,6 +43,9 @@ extern "C" int seeme_debug_h16_times(unsigned long long* host, int n) {
 #ifndef H16_PF
 #define H16_PF 4      // k-blocks of weight fragments in flight in the tile GEMMs (2 -> 4: 1 % of a B=256 pass; the tiles are bound by L2 -> L1 bytes)
 #endif
+#ifndef H16_ALA
+#define H16_ALA 1      // A fragments (LDS) requested this many k-blocks ahead of their MFMAs: 1 or 2
+#endif
 #ifndef FFN_PF
 #define FFN_PF H16_PF  // the FFN's first GEMM (2 n-tiles per wave)
 #endif
@@ -62,34 +65,41 @@ __device__ __forceinline__ void ring_prime(BRing<NTL, PF>& ring, int K32, LoadB 
 template <int MTL, int NTL, int PF, typename LoadB>
 __device__ __forceinline__ void tile_gemm_h16(const unsigned short* __restrict__ As, int lda, int K32, LoadB loadb,
                                               f32x4 (&acc)[MTL][NTL], BRing<NTL, PF>& ring) {
-    static_assert(PF % 2 == 0, "A-fragment ping-pong follows the slot parity");
     const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
     const unsigned short* ap = As + r * lda + 8 * kq;
     // PF k-blocks of B fragments in flight; a slot is re-filled right after the MFMAs that read it.  The scheduler is
     // fenced per k-block: left alone it sinks the re-fills to just before their use (a vmcnt(0) per k-block) and the
     // pipeline collapses -- these tiles are latency-bound, the depth of this pipeline is their speed.
     uint4 (&br)[PF][NTL] = ring.br;                          // primed by the caller (ring_prime)
-    uint4 ab[2][MTL];
+    // A fragments H16_ALA k-blocks ahead (slots indexed by the ring slot u, so PF must be a multiple of H16_ALA + 1 rounded up to
+    // a power of two): read ONE block ahead, a fragment is requested right before an MFMA block of 128 cycles and needed right
+    // after it -- a ds_read_b128 of a 2-way-conflicted operand row under four waves' traffic takes longer than that.
+    constexpr int AS = H16_ALA == 1 ? 2 : 4;
+    static_assert(PF % AS == 0, "A-fragment slots follow the ring slot");
+    uint4 ab[AS][MTL];
 #pragma unroll
-    for (int mt = 0; mt < MTL; ++mt) ab[0][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda);
+    for (int d = 0; d < H16_ALA; ++d)
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt) ab[d][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda + (d < K32 ? d : K32 - 1) * 32);
     // Every k-block of the main loop re-fills its slot UNCONDITIONALLY, the last PF k-blocks (peeled) re-fill nothing: with
     // the re-fill under `if (kb + PF < K32)` the number of loads in flight at the next wait is not a compile-time fact, the
     // compiler assumes the smaller one and emits vmcnt(NTL-1 .. 0) -- which, vmcnt being in-order, waits for the re-fill just
-    // issued: one full L2 round trip per k-block whatever the ring depth (this is why depths 2 and 4 measured the same).
+    // issued: one full L2 round trip per k-block whatever the ring depth.
     const int K32r = (K32 + PF - 1) / PF * PF;
     int kb0 = 0;
     for (; kb0 + PF < K32r; kb0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int kb = kb0 + u;                          // < K32 - 1 here
+            const int ka = kb + H16_ALA < K32 ? kb + H16_ALA : K32 - 1;
 #pragma unroll
-            for (int mt = 0; mt < MTL; ++mt) ab[(u + 1) & 1][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda + (kb + 1) * 32);
+            for (int mt = 0; mt < MTL; ++mt) ab[(u + H16_ALA) % AS][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda + ka * 32);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, ab[u & 1][mt]), __builtin_bit_cast(h16x8, br[u][nt]), acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, ab[u % AS][mt]), __builtin_bit_cast(h16x8, br[u][nt]), acc[mt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef H16_DBG_NOREFILL       // timing-only ablation: the MFMAs keep reading the primed k-blocks (wrong results)
             const int kn = kb + PF < K32 ? kb + PF : K32 - 1;
@@ -101,16 +111,16 @@ __device__ __forceinline__ void tile_gemm_h16(const unsigned short* __restrict__
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int kb = kb0 + u;
-        const int ka = (kb + 1 < K32) ? kb + 1 : K32 - 1;
+        const int ka = (kb + H16_ALA < K32) ? kb + H16_ALA : K32 - 1;
 #pragma unroll
-        for (int mt = 0; mt < MTL; ++mt) ab[(u + 1) & 1][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda + ka * 32);
+        for (int mt = 0; mt < MTL; ++mt) ab[(u + H16_ALA) % AS][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda + ka * 32);
         __builtin_amdgcn_sched_barrier(0);
         if (kb < K32) {
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, ab[u & 1][mt]), __builtin_bit_cast(h16x8, br[u][nt]), acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, ab[u % AS][mt]), __builtin_bit_cast(h16x8, br[u][nt]), acc[mt][nt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -522,14 +532,14 @@ struct AttnHArgs {
 #ifndef ATT_PF
 #define ATT_PF 4    // k-blocks of B operands (K rows, V^T rows, W_o) in flight: the tile is latency-bound, not MFMA-bound
 #endif
-template <int NC>      // NC = Sp / 64 score columns per lane
+template <int NC, int RW = 8>      // NC = Sp / 64 score columns per lane; RW rows per wave
 __device__ __forceinline__ void attn_softmax_rows(const float* Ps, int ldp, unsigned short* Ph, int ldph, int wave, int lane) {
     // Ph MAY ALIAS Ps (no __restrict__): the fp16 probabilities of a row overwrite the head of its own fp32 score row, which
     // is legal because a wave reads all of its 8 rows into registers before it writes any, and no other wave touches them
-    float v[8][NC], mx[8], sum[8];
+    float v[RW][NC], mx[RW], sum[RW];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const float* prow = Ps + (wave * 8 + rr) * ldp + lane;
+    for (int rr = 0; rr < RW; ++rr) {
+        const float* prow = Ps + (wave * RW + rr) * ldp + lane;
 #pragma unroll
         for (int j = 0; j < NC; ++j) v[rr][j] = prow[64 * j];
         mx[rr] = v[rr][0];
@@ -537,19 +547,19 @@ __device__ __forceinline__ void attn_softmax_rows(const float* Ps, int ldp, unsi
         for (int j = 1; j < NC; ++j) mx[rr] = fmaxf(mx[rr], v[rr][j]);
     }
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) mx[rr] = wave_max(mx[rr]);
+    for (int rr = 0; rr < RW; ++rr) mx[rr] = wave_max(mx[rr]);
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
+    for (int rr = 0; rr < RW; ++rr) {
         sum[rr] = 0.f;
 #pragma unroll
         for (int j = 0; j < NC; ++j) { v[rr][j] = h_exp(v[rr][j] - mx[rr]); sum[rr] += v[rr][j]; }
     }
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) sum[rr] = wave_sum(sum[rr]);
+    for (int rr = 0; rr < RW; ++rr) sum[rr] = wave_sum(sum[rr]);
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
+    for (int rr = 0; rr < RW; ++rr) {
         const float inv = __builtin_amdgcn_rcpf(sum[rr]);
-        unsigned short* hrow = Ph + (wave * 8 + rr) * ldph + lane;
+        unsigned short* hrow = Ph + (wave * RW + rr) * ldph + lane;
 #pragma unroll
         for (int j = 0; j < NC; ++j) hrow[64 * j] = f2h(v[rr][j] * inv);
     }
@@ -814,12 +824,12 @@ __device__ __forceinline__ void rows_to_h16(unsigned short* Xh, int ldh, int row
 // (row-major K rows / V^T rows made every wave-load touch 16 rows x 64 B; the V^T rows were written two bytes at a time).
 // Value granules of keys in [S, spv) are written as zeros by the tiles that cover them (P = 0 there, but 0 x garbage is not);
 // key rows in [S, 16 NT16) stay unwritten: their score columns are masked by a select.
-template <int WAVES>
+template <int WAVES, int RW>
 __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned short* Oh, const uint4* __restrict__ qkv_w,
                                               const float* __restrict__ qkv_b, unsigned short* __restrict__ q_out,
                                               uint4* __restrict__ kp_out, uint4* __restrict__ vp_out, int b, int q0, int S, int spv,
                                               BRing<16 / WAVES, H16_PF>& ring_t) {
-    constexpr int ROWS = 8 * WAVES, MTL = ROWS / 16, NTL = 16 / WAVES, CW = 256 / WAVES, NT = 64 * WAVES;
+    constexpr int ROWS = RW * WAVES, MTL = ROWS / 16, NTL = 16 / WAVES, CW = 256 / WAVES, NT = 64 * WAVES;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int ldq = 256 + HPAD;
     const size_t base = (size_t)b * S;
@@ -835,21 +845,21 @@ __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned
         __syncthreads();
         if (y == 0) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
+            for (int it = 0; it < RW / 2; ++it) {
                 const int idx = tid + it * NT, row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
                 if (s < S) *reinterpret_cast<uint4*>(q_out + (base + s) * 256 + c8) = *reinterpret_cast<const uint4*>(Oh + row * ldq + c8);
             }
         } else if (y == 1) {
             uint4* kb_out = kp_out + ((size_t)b * NT16 + (q0 >> 4)) * 512;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
+            for (int it = 0; it < RW / 2; ++it) {
                 const int idx = tid + it * NT, r = idx & 15, kq = (idx >> 4) & 3, kb = (idx >> 6) & 7, half = idx >> 9, row = half * 16 + r;
                 if (q0 + row < S) kb_out[(half * 8 + kb) * 64 + kq * 16 + r] = *reinterpret_cast<const uint4*>(Oh + row * ldq + kb * 32 + kq * 8);
             }
         } else {
             uint4* vb_out = vp_out + (size_t)b * 16 * KB * 64;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
+            for (int it = 0; it < RW / 2; ++it) {
                 const int idx = tid + it * NT, r = idx & 15, g = (idx >> 4) & 3, nt = (idx >> 6) & 15, kh = idx >> 10;   // kh: 32-key block inside the tile
                 const int row0 = 32 * kh + 8 * g, kb = (q0 >> 5) + kh;
                 const unsigned short* src = Oh + row0 * ldq + nt * 16 + r;
@@ -868,9 +878,12 @@ __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned
 
 // debug stamps of a layer that has the next layer's QKV as its tail (the last launch of those in a pass is what is read back)
 #define LAYER_DBG(i) do { if (a.qkv_w != nullptr) H16_DBG(5, i); } while (0)
-template <int WAVES>      // 4: 32 query rows per workgroup (256 threads, LAYER_WPE per CU); 8: 64 rows (512 threads, one per CU) -- half the L2 -> L1 bytes per row
+// <WAVES, RW>: RW rows per wave.  <4, 8>: 32 query rows per workgroup, 256 threads, LAYER_WPE workgroups per CU (large launches);
+// <8, 4>: the same 32 rows on 512 threads, one workgroup per CU -- two waves per SIMD inside every phase (launches that do not fill
+// the chip twice over); <8, 8>: 64 rows on 512 threads (SEEME_LAYER_ROWS=64, measured slower).  All three give identical bits.
+template <int WAVES, int RW>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_layer_h(const LayerHArgs a) {
-    constexpr int ROWS = 8 * WAVES, MTL = ROWS / 16, NTL = 16 / WAVES, CW = 256 / WAVES, N1 = 8 / WAVES, NT = 64 * WAVES;
+    constexpr int ROWS = RW * WAVES, MTL = ROWS / 16, NTL = 16 / WAVES, CW = 256 / WAVES, N1 = 8 / WAVES, NT = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
     const int ldp = a.Sp + LDS_PAD, ldq = 256 + HPAD, ldph = 2 * ldp, ldc = 256 + LDS_PAD;
@@ -895,13 +908,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     {   // Q tile
         uint4 qv[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < RW / 2; ++it) {
             const int idx = tid + it * NT, row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
             qv[it] = *reinterpret_cast<const uint4*>(a.q + (base + (s < a.q_rows ? s : 0)) * 256 + c8);
             if (s >= a.q_rows) qv[it] = make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < RW / 2; ++it) {
             const int idx = tid + it * NT, row = idx >> 5, c8 = (idx & 31) * 8;
             *reinterpret_cast<uint4*>(Qh + row * ldq + c8) = qv[it];
         }
@@ -927,8 +940,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     }
     __syncthreads();
     LAYER_DBG(2);
-    if (a.Sp == 256) attn_softmax_rows<4>(Ps, ldp, Ph, ldph, wave, lane);
-    else attn_softmax_rows<8>(Ps, ldp, Ph, ldph, wave, lane);
+    if (a.Sp == 256) attn_softmax_rows<4, RW>(Ps, ldp, Ph, ldph, wave, lane);
+    else attn_softmax_rows<8, RW>(Ps, ldp, Ph, ldph, wave, lane);
     __syncthreads();
     LAYER_DBG(3);
     {   // O = P V
@@ -963,35 +976,35 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     __syncthreads();
     LAYER_DBG(5);
     unsigned short* Xh = R1;
-    float4 x1[8];
+    float4 x1[RW];
     {   // +residual, LN1 [, + cross-attention vector, LN]; rows stay in registers, fp16 copy is the FFN operand
         const LnParams lp = ln_params256_opt(a.n1_w, a.n1_b, a.n1_w), lc = ln_params256_opt(a.lnc_w, a.lnc_b, a.n1_w);
-        float4 xr[8];
+        float4 xr[RW];
         const float4 cv = *reinterpret_cast<const float4*>((a.cvec != nullptr ? a.cvec + (size_t)b * a.cvec_ld : a.n1_w) + lane * 4);
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int s = q0 + wave * 8 + rr;
+        for (int rr = 0; rr < RW; ++rr) {
+            const int s = q0 + wave * RW + rr;
             xr[rr] = *reinterpret_cast<const float4*>(a.res + (base + (s < a.q_rows ? s : 0)) * 256 + lane * 4);
         }
         __builtin_amdgcn_sched_barrier(0);
         LAYER_DBG(16);
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const float4 v = *reinterpret_cast<const float4*>(Cs + (wave * 8 + rr) * ldc + lane * 4);
+        for (int rr = 0; rr < RW; ++rr) {
+            const float4 v = *reinterpret_cast<const float4*>(Cs + (wave * RW + rr) * ldc + lane * 4);
             x1[rr] = make_float4(v.x + xr[rr].x, v.y + xr[rr].y, v.z + xr[rr].z, v.w + xr[rr].w);
         }
         LAYER_DBG(17);
-        wave_layernorm256_x8(x1, lp, a.eps);
+        wave_layernorm256_rows<RW>(x1, lp, a.eps);
         LAYER_DBG(18);
         if (a.cvec != nullptr) {
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) x1[rr] = make_float4(x1[rr].x + cv.x, x1[rr].y + cv.y, x1[rr].z + cv.z, x1[rr].w + cv.w);
-            wave_layernorm256_x8(x1, lc, a.eps);
+            for (int rr = 0; rr < RW; ++rr) x1[rr] = make_float4(x1[rr].x + cv.x, x1[rr].y + cv.y, x1[rr].z + cv.z, x1[rr].w + cv.w);
+            wave_layernorm256_rows<RW>(x1, lc, a.eps);
         }
         LAYER_DBG(19);
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int row = wave * 8 + rr;
+        for (int rr = 0; rr < RW; ++rr) {
+            const int row = wave * RW + rr;
             if (q0 + row >= a.q_rows) x1[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
             rows_to_h16(Xh, ldq, row, lane, x1[rr]);
         }
@@ -1026,17 +1039,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     LAYER_DBG(8);
     {   // +residual, LN [, stack LN]; layer output rows
         const LnParams lp = ln_params256_opt(a.n2_w, a.n2_b, a.n2_w), lf = ln_params256_opt(a.fin_w, a.fin_b, a.n2_w);
-        float4 v[8];
+        float4 v[RW];
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const float4 c = *reinterpret_cast<const float4*>(Cs + (wave * 8 + rr) * ldc + lane * 4);
+        for (int rr = 0; rr < RW; ++rr) {
+            const float4 c = *reinterpret_cast<const float4*>(Cs + (wave * RW + rr) * ldc + lane * 4);
             v[rr] = make_float4(c.x + x1[rr].x, c.y + x1[rr].y, c.z + x1[rr].z, c.w + x1[rr].w);
         }
-        wave_layernorm256_x8(v, lp, a.eps);
-        if (a.fin_w != nullptr) wave_layernorm256_x8(v, lf, a.eps);
+        wave_layernorm256_rows<RW>(v, lp, a.eps);
+        if (a.fin_w != nullptr) wave_layernorm256_rows<RW>(v, lf, a.eps);
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int row = wave * 8 + rr, s = q0 + row;
+        for (int rr = 0; rr < RW; ++rr) {
+            const int row = wave * RW + rr, s = q0 + row;
             if (s >= a.q_rows) v[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.out != nullptr && s < a.q_rows) {
                 const size_t orow = a.out_mode == 1 ? (size_t)s * a.B + b : base + s;
@@ -1051,15 +1064,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     if (a.skip_w != nullptr) {   // x = W_skip . cat(x, skip rows) + b : two K = 256 halves, the second operand tile in R0
         unsigned short* Sh = reinterpret_cast<unsigned short*>(R0);
         {
-            float4 sv[8];
+            float4 sv[RW];
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int s = q0 + wave * 8 + rr;
+            for (int rr = 0; rr < RW; ++rr) {
+                const int s = q0 + wave * RW + rr;
                 sv[rr] = *reinterpret_cast<const float4*>(a.skip_src + (base + (s < a.S ? s : 0)) * 256 + lane * 4);
                 if (s >= a.S) sv[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) rows_to_h16(Sh, ldq, wave * 8 + rr, lane, sv[rr]);
+            for (int rr = 0; rr < RW; ++rr) rows_to_h16(Sh, ldq, wave * RW + rr, lane, sv[rr]);
         }
         const BiasRegs<NTL> bias_s = bias_load<NTL>(a.skip_b, wave * CW, 256);
         __syncthreads();
@@ -1072,8 +1085,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
         acc_store_lds<MTL, NTL>(acc, Cs, ldc, wave * CW, bias_s, SEEME_ACT_NONE);
         __syncthreads();
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int row = wave * 8 + rr, s = q0 + row;
+        for (int rr = 0; rr < RW; ++rr) {
+            const int row = wave * RW + rr, s = q0 + row;
             float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + lane * 4);
             if (s >= a.S) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (s < a.S) *reinterpret_cast<float4*>(a.xnext + (base + s) * 256 + lane * 4) = v;
@@ -1083,7 +1096,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     }
     LAYER_DBG(10);
     if (a.qkv_w != nullptr) {    // q | k | V^T of the next layer for these rows, into the other buffer set
-        tail_qkv_rows<WAVES>(Xh, reinterpret_cast<unsigned short*>(R0), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
+        tail_qkv_rows<WAVES, RW>(Xh, reinterpret_cast<unsigned short*>(R0), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
         LAYER_DBG(11);
         return;
     }
@@ -1102,28 +1115,28 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     }
 }
 
-// 32 query rows per workgroup by default.  The 64-row instantiation (SEEME_LAYER_ROWS=64; Sp <= 256 only: 102 KB of LDS) pulls
-// half the weight / K / V bytes per row from L2 and produces bit-identical results, and measures 1-2 % SLOWER at B = 256 / 512
-// (DESIGN.md section 5.2): L2 -> L1 bytes are not what bounds these tiles.
-static int layer_rows(const LayerHArgs& a) {
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("SEEME_LAYER_ROWS"); forced = e ? atoi(e) : 0; }
-    return (forced == 64 && a.Sp <= 256 && a.q_rows > 32) ? 64 : 32;
-}
-template <int WAVES>
+// 32 query rows per workgroup.  The 64-row instantiation (SEEME_LAYER_ROWS=64; Sp <= 256 only: 102 KB of LDS) pulls half the
+// weight / K / V bytes per row from L2 and measures 1-2 % SLOWER at B = 256 / 512.  Launches of at most
+// SEEME_LAYER_W8_MAX workgroups (default 320: B = 32 at T = 196 is 224) run their 32 rows on 8 waves instead of 4.
+template <int WAVES, int RW>
 static int launch_layer_w(const LayerHArgs& a, hipStream_t st) {
-    constexpr int ROWS = 8 * WAVES;
+    constexpr int ROWS = RW * WAVES;
     const size_t lds = (size_t)ROWS * (a.Sp + LDS_PAD) * 4 + (size_t)ROWS * (256 + HPAD) * 2;
     dim3 grid((a.q_rows + ROWS - 1) / ROWS, a.B);
-    SEEME_HIP(hipFuncSetAttribute((const void*)k_layer_h<WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_layer_h<WAVES>, grid, dim3(64 * WAVES), lds, st, a);
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_layer_h<WAVES, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_layer_h<WAVES, RW>), grid, dim3(64 * WAVES), lds, st, a);
     return seeme_check_launch("k_layer_h");
 }
 static int launch_layer_h(const LayerHArgs& a_in, hipStream_t st) {
     LayerHArgs a = a_in;
     if (a.S <= 0 || a.S > 512) return seeme_fail("layer_h: S must be in 1..512");
     a.Sp = (a.S + CH_N - 1) / CH_N * CH_N;
-    return layer_rows(a) == 64 ? launch_layer_w<8>(a, st) : launch_layer_w<4>(a, st);
+    static int rows = -1, w8_max = -1;
+    if (rows < 0) { const char* e = getenv("SEEME_LAYER_ROWS"); rows = e ? atoi(e) : 32; }
+    if (w8_max < 0) { const char* e = getenv("SEEME_LAYER_W8_MAX"); w8_max = e ? atoi(e) : 320; }
+    if (rows == 64 && a.Sp <= 256 && a.q_rows > 32) return launch_layer_w<8, 8>(a, st);
+    const long wgs = (long)a.B * ((a.q_rows + 31) / 32);
+    return wgs <= w8_max ? launch_layer_w<8, 4>(a, st) : launch_layer_w<4, 8>(a, st);
 }
 
 
@@ -1177,7 +1190,7 @@ __global__ __launch_bounds__(256) void k_vae_pro_h(const ProHArgs a) {
         rows_to_h16(Xh, ldq, row, lane, v);
     }
     __syncthreads();
-    tail_qkv_rows<4>(Xh, reinterpret_cast<unsigned short*>(Cs), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
+    tail_qkv_rows<4, 8>(Xh, reinterpret_cast<unsigned short*>(Cs), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
 }
 static int launch_pro_h(const ProHArgs& a, hipStream_t st) {
     if (a.mode == 1 && a.F > 256) return seeme_fail("vae_pro_h: nfeats > 256");

@@ -551,8 +551,9 @@ def test_bench_modes_emit_the_contract_line(dev, argv, checks):
 
 
 def test_launch_mapping_knobs_do_not_change_results(dev, tmp_path):
-    """SEEME_DEN_XCDS (which XCDs the sampling kernel's working workgroups sit on; default ceil(chains / 16)) and SEEME_LAYER_ROWS
-    (32- or 64-row workgroups of the per-layer VAE kernel) only move work around: VAE encode / decode and a 5-step DDIM sample on
+    """SEEME_DEN_XCDS (which XCDs the sampling kernel's working workgroups sit on; default ceil(chains / 16)), SEEME_LAYER_ROWS
+    (32- or 64-row workgroups of the per-layer VAE kernel) and SEEME_LAYER_W8_MAX (up to how many workgroups a launch runs its 32
+    rows on 8 waves instead of 4) only move work around: VAE encode / decode and a 5-step DDIM sample on
     fixed inputs (scripts/launch_knobs_probe.py, one child process per setting -- the knobs are read once per process) must be
     bit-identical to the default.  B = 37 gives ragged lengths, an odd chain count and partial XCD rounds."""
     import subprocess
@@ -560,7 +561,7 @@ def test_launch_mapping_knobs_do_not_change_results(dev, tmp_path):
     probe = os.path.join(REPO, "scripts", "launch_knobs_probe.py")
     outs = {}
     for tag, env in (("default", {}), ("xcds1", {"SEEME_DEN_XCDS": "1"}), ("xcds5", {"SEEME_DEN_XCDS": "5"}), ("xcds8", {"SEEME_DEN_XCDS": "8"}),
-                     ("rows64", {"SEEME_LAYER_ROWS": "64"})):
+                     ("rows64", {"SEEME_LAYER_ROWS": "64"}), ("waves4", {"SEEME_LAYER_W8_MAX": "0"})):
         f = str(tmp_path / (tag + ".pt"))
         r = subprocess.run([sys.executable, probe, f, "37"], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
         assert r.returncode == 0, (tag, r.stderr[-2000:])
