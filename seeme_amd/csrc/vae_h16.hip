@@ -92,8 +92,10 @@ __device__ __forceinline__ void tile_gemm_h16(const unsigned short* __restrict__
         for (int u = 0; u < PF; ++u) {
             const int kb = kb0 + u;                          // < K32 - 1 here
             const int ka = kb + H16_ALA < K32 ? kb + H16_ALA : K32 - 1;
+#ifndef H16_DBG_NOAREAD        // timing-only ablation: the A fragments of the first k-blocks are reused (wrong results)
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt) ab[(u + H16_ALA) % AS][mt] = *reinterpret_cast<const uint4*>(ap + mt * 16 * lda + ka * 32);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt)
