@@ -80,44 +80,62 @@ __device__ __forceinline__ void tile_gemm_f32(const float* __restrict__ As, int 
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) br[u][nt] = *reinterpret_cast<const float4*>(wp[nt] + kk * 16);
     }
-    for (int kb0 = 0; kb0 < K16; kb0 += PF) {
+    // Main loop: every k-block re-fills its slot UNCONDITIONALLY; the last PF k-blocks are peeled and re-fill nothing.  With the
+    // re-fill under `if (kb + PF < K16)` the number of loads in flight at the next wait is not a compile-time fact: the compiler
+    // assumes the smaller one and waits with vmcnt(NTL-1 .. 0), i.e. -- vmcnt being in-order -- for the re-fill just issued: one
+    // L2 round trip per k-block whatever PF (a 32-row x 4608-column table GEMM took 24 us that way).
+    auto block = [&](int kb, int u, bool refill) {
+        float4 a[MTL], b[NTL];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int kb = kb0 + u;
-            if (kb < K16) {
-                float4 a[MTL], b[NTL];
+        for (int nt = 0; nt < NTL; ++nt) b[nt] = br[u][nt];
 #pragma unroll
-                for (int nt = 0; nt < NTL; ++nt) b[nt] = br[u][nt];
+        for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
+        // the slot is re-filled HERE, above this k-block's MFMAs, and the scheduler is fenced: left alone it
+        // sinks the loads to just before their use (vmcnt(0) per k-block: one L2 round trip per 16 k)
+        if (refill) {
+            const int kn = kb + PF < K16 ? kb + PF : K16 - 1;
 #pragma unroll
-                for (int mt = 0; mt < MTL; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + mt * 16 * lda + kb * 16);
-                // the slot is re-filled HERE, above this k-block's MFMAs, and the scheduler is fenced: left alone it
-                // sinks the loads to just before their use (vmcnt(0) per k-block: one L2 round trip per 16 k)
-                if (kb + PF < K16) {
-#pragma unroll
-                    for (int nt = 0; nt < NTL; ++nt) br[u][nt] = *reinterpret_cast<const float4*>(wp[nt] + (kb + PF) * 16);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // j outermost: MTL*NTL independent accumulators between two uses of the same one
-                // (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency)
-#pragma unroll
-                for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int nt = 0; nt < NTL; ++nt) br[u][nt] = *reinterpret_cast<const float4*>(wp[nt] + kn * 16);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // j outermost: MTL*NTL independent accumulators between two uses of the same one
+        // (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency)
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (K16 == 16) {
+        // K = 256 (every projection of the path): fully unrolled.  As a real loop the ring's loop-carried registers get copies
+        // on the back-edge, and a copy of a register with a load in flight is a vmcnt(0) -- the pipeline drained every PF k-blocks.
+#pragma unroll
+        for (int kb = 0; kb < 12; ++kb) block(kb, kb % PF, true);
+#pragma unroll
+        for (int kb = 12; kb < 16; ++kb) block(kb, kb % PF, false);
+        return;
+    }
+    const int K16r = (K16 + PF - 1) / PF * PF;
+    int kb0 = 0;
+    for (; kb0 + PF < K16r; kb0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) block(kb0 + u, u, true);       // kb0 + u <= K16 - 2 here
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        if (kb0 + u < K16) block(kb0 + u, u, false);
     }
 }
 
