@@ -30,6 +30,7 @@ struct LinearKArgs {
     // optional batch of independent problems over blockIdx.z (element strides per z; nz = 0 or 1: single problem)
     int nz;
     long zs_a, zs_w, zs_b, zs_y, zs_ln;
+    int narrow;      // (set by the launcher) 64 output columns per workgroup, 16 per wave: few-row problems spread over 4x the CUs
 };
 int seeme_launch_linear(const LinearKArgs& ka, hipStream_t st);
 int seeme_linear_simple(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias,

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
     float* Cs = smem + TILE_M * lda_s;      // [32][256+8]
     const int ldc = CH_N + LDS_PAD;
     const int m0 = blockIdx.x * TILE_M;
-    const int cn0 = blockIdx.y * CH_N;
+    const int cn0 = blockIdx.y * (ka.narrow ? 64 : CH_N);
 
     // ---- stage A tile (zero padded), optional pre-LN and pre-activation
     const bool a_vec = (a.A2 == nullptr) && ((a.K & 3) == 0) && ((a.lda & 3) == 0) && ((reinterpret_cast<size_t>(a.A) & 15) == 0);
@@ -89,11 +89,19 @@ __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
     }
 
     // ---- GEMM: wave w owns tile columns [64w, 64w+64)
-    f32x4 acc[2][4];
-    acc_zero(acc);
-    const int n0 = cn0 + wave * 64;
-    if (n0 < a.N) tile_gemm_f32<2, 4>(As, lda_s, a.W, a.ldw, n0, a.N, Kp >> 4, acc);
-    acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, a.bias, cn0, a.N, a.act);
+    if (ka.narrow) {    // one n-tile per wave: a 32-row problem with thousands of columns is matrix-core time on N / 256 CUs otherwise
+        f32x4 acc[2][1];
+        acc_zero(acc);
+        const int n0 = cn0 + wave * 16;
+        if (n0 < a.N) tile_gemm_f32<2, 1>(As, lda_s, a.W, a.ldw, n0, a.N, Kp >> 4, acc);
+        acc_store_lds<2, 1>(acc, Cs, ldc, wave * 16, a.bias, cn0, a.N, a.act);
+    } else {
+        f32x4 acc[2][4];
+        acc_zero(acc);
+        const int n0 = cn0 + wave * 64;
+        if (n0 < a.N) tile_gemm_f32<2, 4>(As, lda_s, a.W, a.ldw, n0, a.N, Kp >> 4, acc);
+        acc_store_lds<2, 4>(acc, Cs, ldc, wave * 64, a.bias, cn0, a.N, a.act);
+    }
     __syncthreads();
 
     // ---- row pass: residual, LayerNorm, coalesced store.  wave w -> rows 8w..8w+7, lane -> 4 cols
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
     for (int rr = 0; rr < 8; ++rr) {
         rv[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (res_vec) {
-            const int m = m0 + wave * 8 + rr, mc = m < a.M ? m : 0, g = cn0 + lane * 4;
+            const int m = m0 + wave * 8 + rr, mc = m < a.M ? m : 0, g = (ka.narrow && lane >= 16) ? a.N : cn0 + lane * 4;
             int orow = mc;
             if (ka.seq_in > 0) orow = (mc / ka.seq_in) * ka.out_stride + (mc % ka.seq_in) + ka.out_off;
             const size_t rrow = ka.res_mode == 1 ? (size_t)((mc % ka.seq_in) + ka.res_off)
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
         if (m >= a.M) continue;  // wave-uniform
         int orow = m;
         if (ka.seq_in > 0) orow = (m / ka.seq_in) * ka.out_stride + (m % ka.seq_in) + ka.out_off;
-        const int c = lane * 4, g = cn0 + c;
+        const int c = (ka.narrow && lane >= 16) ? 0 : lane * 4, g = (ka.narrow && lane >= 16) ? a.N : cn0 + c;
         float4 v = *reinterpret_cast<const float4*>(Cs + row * ldc + c);
         if (res_vec) {
             v = make_float4(v.x + rv[rr].x, v.y + rv[rr].y, v.z + rv[rr].z, v.w + rv[rr].w);
@@ -159,9 +167,13 @@ int seeme_launch_linear(const LinearKArgs& ka, hipStream_t st) {
     if ((a.ldw & 3) != 0) return seeme_fail("seeme_linear: ldw must be a multiple of 4");
     if (Kp > 1024) return seeme_fail("seeme_linear: K > 1024 not supported");
     const size_t lds = (size_t)(TILE_M * (Kp + LDS_PAD) + TILE_M * (CH_N + LDS_PAD)) * sizeof(float);
-    dim3 grid((a.M + TILE_M - 1) / TILE_M, (a.N + CH_N - 1) / CH_N, ka.nz > 1 ? ka.nz : 1);
+    LinearKArgs k2 = ka;
+    const long wide = (long)((a.M + TILE_M - 1) / TILE_M) * ((a.N + CH_N - 1) / CH_N) * (ka.nz > 1 ? ka.nz : 1);
+    k2.narrow = (a.ln_w == nullptr && a.N >= 512 && wide <= 64) ? 1 : 0;     // too few 256-column workgroups to matter to 256 CUs
+    const int cw = k2.narrow ? 64 : CH_N;
+    dim3 grid((a.M + TILE_M - 1) / TILE_M, (a.N + cw - 1) / cw, ka.nz > 1 ? ka.nz : 1);
     SEEME_HIP(hipFuncSetAttribute((const void*)k_linear, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_linear, grid, dim3(256), lds, st, ka);
+    hipLaunchKernelGGL(k_linear, grid, dim3(256), lds, st, k2);
     return seeme_check_launch("k_linear");
 }
 
