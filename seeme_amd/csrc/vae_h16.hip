@@ -797,6 +797,9 @@ static int launch_ffn_h(const FfnHArgs& a, hipStream_t st) {
 #ifndef LAYER_KV_PF
 #define LAYER_KV_PF 4    // k-blocks of K rows / V^T rows in flight in k_layer_h's two attention GEMMs
 #endif
+#ifndef LAYER_W8_PF
+#define LAYER_W8_PF 4    // k-blocks in flight in the 8-wave instantiation (4 or 8)
+#endif
 #ifndef LAYER_WPE
 #define LAYER_WPE 2      // workgroups per CU the register allocation aims at (3 would need <= 168 VGPRs)
 #endif
@@ -826,11 +829,11 @@ __device__ __forceinline__ void rows_to_h16(unsigned short* Xh, int ldh, int row
 // (row-major K rows / V^T rows made every wave-load touch 16 rows x 64 B; the V^T rows were written two bytes at a time).
 // Value granules of keys in [S, spv) are written as zeros by the tiles that cover them (P = 0 there, but 0 x garbage is not);
 // key rows in [S, 16 NT16) stay unwritten: their score columns are masked by a select.
-template <int WAVES, int RW>
+template <int WAVES, int RW, int PF>
 __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned short* Oh, const uint4* __restrict__ qkv_w,
                                               const float* __restrict__ qkv_b, unsigned short* __restrict__ q_out,
                                               uint4* __restrict__ kp_out, uint4* __restrict__ vp_out, int b, int q0, int S, int spv,
-                                              BRing<16 / WAVES, H16_PF>& ring_t) {
+                                              BRing<16 / WAVES, PF>& ring_t) {
     constexpr int ROWS = RW * WAVES, MTL = ROWS / 16, NTL = 16 / WAVES, CW = 256 / WAVES, NT = 64 * WAVES;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int ldq = 256 + HPAD;
@@ -840,7 +843,7 @@ __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned
         f32x4 acc[MTL][NTL];
         acc_zero(acc);
         const BiasRegs<NTL> bias = bias_load<NTL>(qkv_b, y * 256 + wave * CW, 768);
-        gemm_packed<MTL, NTL>(Xh, ldq, qkv_w, 8, y * 16 + wave * NTL, 48, 8, acc, ring_t);
+        gemm_packed<MTL, NTL, PF>(Xh, ldq, qkv_w, 8, y * 16 + wave * NTL, 48, 8, acc, ring_t);
         if (y < 2) prime_packed(ring_t, qkv_w, 8, (y + 1) * 16 + wave * NTL, 48, 8);
         __syncthreads();                    // the previous part's stores have read the output tile
         acc_store_h16<MTL, NTL>(acc, Oh, ldq, wave * CW, bias, SEEME_ACT_NONE);
@@ -886,6 +889,9 @@ __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned
 template <int WAVES, int RW>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_layer_h(const LayerHArgs a) {
     constexpr int ROWS = RW * WAVES, MTL = ROWS / 16, NTL = 16 / WAVES, CW = 256 / WAVES, N1 = 8 / WAVES, NT = 64 * WAVES;
+    // k-blocks of B fragments in flight: the 8-wave / 4-row form has the registers to request a whole K = 256 operand at once
+    constexpr int PFW = (WAVES == 8 && RW == 4) ? LAYER_W8_PF : H16_PF, PFA = (WAVES == 8 && RW == 4) ? LAYER_W8_PF : ATT_PF,
+                  PFK = (WAVES == 8 && RW == 4) ? LAYER_W8_PF : LAYER_KV_PF, PFF = (WAVES == 8 && RW == 4) ? LAYER_W8_PF : FFN_PF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
     const int ldp = a.Sp + LDS_PAD, ldq = 256 + HPAD, ldph = 2 * ldp, ldc = 256 + LDS_PAD;
@@ -904,7 +910,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     const size_t base = (size_t)b * a.S;
     const int n_valid_keys = min(a.S, a.n_prefix + a.lengths[b]);
     const BiasRegs<NTL> bias_o = bias_load<NTL>(a.bo, wave * CW, 256);
-    BRing<NTL, ATT_PF> ring_o;
+    BRing<NTL, PFA> ring_o;
     prime_packed(ring_o, a.wo, 8, wave * NTL, 16, 8);
     LAYER_DBG(0);
     {   // Q tile
@@ -929,7 +935,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
         const int n0 = c0 + wave * CW;
         f32x4 acc[MTL][NTL];
         acc_zero(acc);
-        if (n0 < a.S) gemm_packed<MTL, NTL, LAYER_KV_PF>(Qh, ldq, Kp, 8, n0 >> 4, NT16, 8, acc);
+        if (n0 < a.S) gemm_packed<MTL, NTL, PFK>(Qh, ldq, Kp, 8, n0 >> 4, NT16, 8, acc);
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
             const int c = n0 + nt * 16 + r;
@@ -950,7 +956,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
         f32x4 acc[MTL][NTL];
         acc_zero(acc);
         const int K32 = (n_valid_keys + 31) >> 5;
-        gemm_packed<MTL, NTL, LAYER_KV_PF>(Ph, ldph, a.vp + (size_t)b * 16 * (a.spv >> 5) * 64, a.spv >> 5, wave * NTL, 16, K32, acc);
+        gemm_packed<MTL, NTL, PFK>(Ph, ldph, a.vp + (size_t)b * 16 * (a.spv >> 5) * 64, a.spv >> 5, wave * NTL, 16, K32, acc);
         acc_store_h16<MTL, NTL>(acc, Qh, ldq, wave * CW, nullptr, SEEME_ACT_NONE);
     }
     __syncthreads();
@@ -959,7 +965,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     {
         f32x4 acc[MTL][NTL];
         acc_zero(acc);
-        gemm_packed<MTL, NTL, ATT_PF>(Qh, ldq, a.wo, 8, wave * NTL, 16, 8, acc, ring_o);
+        gemm_packed<MTL, NTL, PFA>(Qh, ldq, a.wo, 8, wave * NTL, 16, 8, acc, ring_o);
 #ifdef H16_DBG_TIMES
         asm volatile("" : "+v"(acc[0][0][0]), "+v"(acc[MTL - 1][NTL - 1][3]));
         LAYER_DBG(23);
@@ -970,8 +976,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     // FFN weights requested now: their cold miss overlaps LN1
     const BiasRegs<N1> bias1 = bias_load<N1>(a.b1, wave * (128 / WAVES), 128);
     const BiasRegs<NTL> bias2 = bias_load<NTL>(a.b2, wave * CW, 256);
-    BRing<N1, FFN_PF> ring1;
-    BRing<NTL, H16_PF> ring2;
+    BRing<N1, PFF> ring1;
+    BRing<NTL, PFW> ring2;
     prime_packed(ring1, a.w1, 8, wave * N1, 8, 8);
     prime_packed(ring2, a.w2, 4, wave * NTL, 16, 4);
     LAYER_DBG(25);
@@ -1019,7 +1025,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     {
         f32x4 acc1[MTL][N1];
         acc_zero(acc1);
-        gemm_packed<MTL, N1, FFN_PF>(Xh, ldq, a.w1, 8, wave * N1, 8, 8, acc1, ring1);
+        gemm_packed<MTL, N1, PFF>(Xh, ldq, a.w1, 8, wave * N1, 8, 8, acc1, ring1);
         __syncthreads();
         acc_store_h16<MTL, N1>(acc1, Hh, ldhh, wave * (128 / WAVES), bias1, SEEME_ACT_GELU);
     }
@@ -1028,12 +1034,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     {
         f32x4 acc2[MTL][NTL];
         acc_zero(acc2);
-        gemm_packed<MTL, NTL>(Hh, ldhh, a.w2, 4, wave * NTL, 16, 4, acc2, ring2);
+        gemm_packed<MTL, NTL, PFW>(Hh, ldhh, a.w2, 4, wave * NTL, 16, 4, acc2, ring2);
         acc_store_lds<MTL, NTL>(acc2, Cs, ldc, wave * CW, bias2, SEEME_ACT_NONE);
     }
     // tail weights requested now
     const bool has_tail = a.skip_w != nullptr || a.qkv_w != nullptr || a.proj_w != nullptr;
-    BRing<NTL, H16_PF> ring_t;
+    BRing<NTL, PFW> ring_t;
     if (a.skip_w != nullptr) prime_packed(ring_t, a.skip_w, 16, wave * NTL, 16, 8);
     else if (a.qkv_w != nullptr) prime_packed(ring_t, a.qkv_w, 8, wave * NTL, 48, 8);
     else if (a.proj_w != nullptr) prime_packed(ring_t, a.proj_w, 8, wave * NTL, (a.F + 15) >> 4, 8);
@@ -1080,8 +1086,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
         __syncthreads();
         f32x4 acc[MTL][NTL];
         acc_zero(acc);
-        gemm_packed<MTL, NTL>(Xh, ldq, a.skip_w, 16, wave * NTL, 16, 8, acc, ring_t);
-        gemm_packed<MTL, NTL>(Sh, ldq, a.skip_w + 8 * 64, 16, wave * NTL, 16, 8, acc);
+        gemm_packed<MTL, NTL, PFW>(Xh, ldq, a.skip_w, 16, wave * NTL, 16, 8, acc, ring_t);
+        gemm_packed<MTL, NTL, PFW>(Sh, ldq, a.skip_w + 8 * 64, 16, wave * NTL, 16, 8, acc);
         if (a.qkv_w != nullptr) prime_packed(ring_t, a.qkv_w, 8, wave * NTL, 48, 8);
         __syncthreads();
         acc_store_lds<MTL, NTL>(acc, Cs, ldc, wave * CW, bias_s, SEEME_ACT_NONE);
@@ -1098,7 +1104,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     }
     LAYER_DBG(10);
     if (a.qkv_w != nullptr) {    // q | k | V^T of the next layer for these rows, into the other buffer set
-        tail_qkv_rows<WAVES, RW>(Xh, reinterpret_cast<unsigned short*>(R0), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
+        tail_qkv_rows<WAVES, RW, PFW>(Xh, reinterpret_cast<unsigned short*>(R0), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
         LAYER_DBG(11);
         return;
     }
@@ -1107,7 +1113,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
         const BiasRegs<NTL> bias = bias_load<NTL>(a.proj_b, wave * CW, a.F);
         f32x4 acc[MTL][NTL];
         acc_zero(acc);
-        if (wave * NTL < ntiles) gemm_packed<MTL, NTL>(Xh, ldq, a.proj_w, 8, wave * NTL, ntiles, 8, acc, ring_t);
+        if (wave * NTL < ntiles) gemm_packed<MTL, NTL, PFW>(Xh, ldq, a.proj_w, 8, wave * NTL, ntiles, 8, acc, ring_t);
         acc_store_lds<MTL, NTL>(acc, Cs, ldc, wave * CW, bias, SEEME_ACT_NONE);
         __syncthreads();
         for (int idx = tid; idx < ROWS * 256; idx += NT) {
@@ -1192,7 +1198,7 @@ __global__ __launch_bounds__(256) void k_vae_pro_h(const ProHArgs a) {
         rows_to_h16(Xh, ldq, row, lane, v);
     }
     __syncthreads();
-    tail_qkv_rows<4, 8>(Xh, reinterpret_cast<unsigned short*>(Cs), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
+    tail_qkv_rows<4, 8, H16_PF>(Xh, reinterpret_cast<unsigned short*>(Cs), a.qkv_w, a.qkv_b, a.q_out, a.kp_out, a.vp_out, b, q0, a.S, a.spv, ring_t);
 }
 static int launch_pro_h(const ProHArgs& a, hipStream_t st) {
     if (a.mode == 1 && a.F > 256) return seeme_fail("vae_pro_h: nfeats > 256");
