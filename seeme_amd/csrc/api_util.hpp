@@ -30,6 +30,7 @@ struct LinearKArgs {
     // optional batch of independent problems over blockIdx.z (element strides per z; nz = 0 or 1: single problem)
     int nz;
     long zs_a, zs_w, zs_b, zs_y, zs_ln;
+    int pre_ln_zmin; // batched problems: the pre-LayerNorm applies to members z >= pre_ln_zmin only (0: to all)
     int narrow;      // (set by the launcher) 64 output columns per workgroup, 16 per wave: few-row problems spread over 4x the CUs
 };
 int seeme_launch_linear(const LinearKArgs& ka, hipStream_t st);

@@ -1077,16 +1077,19 @@ extern "C" int seeme_denoiser_cond_tables(const SeemeDenoiserWeights* w, const f
     (void)workspace; (void)ws_bytes;
     hipStream_t st = (hipStream_t)stream;
     const int M = Bc * N;
-    int rc;
-    // sa_block K|V of the condition tokens, all layers at once
-    if ((rc = seeme_linear_simple(st, cond, 256, w->kv_cat_w, 256, w->kv_cat_b, ctab, SEEME_CROW, M, 2560, 256, 0, 0, nullptr, nullptr))) return rc;
-    // ca_block: key|value of text_norm(xf) for all layers in one GEMM -- the per-layer LayerNorm affine is
-    // folded into the weights, so the input is the affine-free LayerNorm of the condition
-    // (mdiff_transformer.py:230,234); the token softmax of the keys is applied in-kernel
+    // Two GEMMs on the same rows as ONE batched launch (z = 0, 1):
+    //   z = 0: sa_block K|V of the condition tokens, all layers at once -> ctab[:, 0:2560]
+    //   z = 1: ca_block key|value of text_norm(xf) for all layers -- the per-layer LayerNorm affine is folded into the weights, so
+    //          the input is the affine-free LayerNorm of the condition (mdiff_transformer.py:230,234); the token softmax of the
+    //          keys is applied in-kernel -> ctab[:, 2560:5120]
     if (w->ca_fold_w == nullptr) return seeme_fail("cond_tables: folded key/value weights missing");
-    if ((rc = seeme_linear_simple(st, cond, 256, w->ca_fold_w, 256, w->ca_fold_b, ctab + 2560, SEEME_CROW, M, 2560, 256, 0, 0,
-                                  w->ln_ones, w->ln_zeros))) return rc;
-    return 0;
+    LinearKArgs ka{};
+    ka.a.A = cond; ka.a.lda = 256; ka.a.K1 = 256; ka.a.K = 256; ka.a.W = w->kv_cat_w; ka.a.ldw = 256; ka.a.bias = w->kv_cat_b;
+    ka.a.Y = ctab; ka.a.ldy = SEEME_CROW; ka.a.M = M; ka.a.N = 2560; ka.a.eps = 1e-5f;
+    ka.a.pre_ln_w = w->ln_ones; ka.a.pre_ln_b = w->ln_zeros;
+    ka.nz = 2; ka.zs_a = 0; ka.zs_w = (long)(w->ca_fold_w - w->kv_cat_w); ka.zs_b = (long)(w->ca_fold_b - w->kv_cat_b); ka.zs_y = 2560;
+    ka.zs_ln = 0; ka.pre_ln_zmin = 1;
+    return seeme_launch_linear(ka, st);
 }
 
 // ------------------------------------------------------------------ ca_block table for ONE condition token

@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
         a.A += z * ka.zs_a; a.W += z * ka.zs_w; a.Y += z * ka.zs_y;
         if (a.bias) a.bias += z * ka.zs_b;
         if (a.pre_ln_w) { a.pre_ln_w += z * ka.zs_ln; a.pre_ln_b += z * ka.zs_ln; }
+        if (z < ka.pre_ln_zmin) { a.pre_ln_w = nullptr; a.pre_ln_b = nullptr; }
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Kp = (a.K + 15) & ~15;
