@@ -158,6 +158,12 @@ __global__ __launch_bounds__(256) void k_linear(const LinearKArgs ka) {
     }
 }
 
+#ifndef SEEME_NARROW_MIN_N
+#define SEEME_NARROW_MIN_N 512
+#endif
+#ifndef SEEME_NARROW_MAX
+#define SEEME_NARROW_MAX 64
+#endif
 int seeme_launch_linear(const LinearKArgs& ka, hipStream_t st) {
     const SeemeLinearArgs& a = ka.a;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return seeme_fail("seeme_linear: empty problem");
@@ -170,7 +176,7 @@ int seeme_launch_linear(const LinearKArgs& ka, hipStream_t st) {
     const size_t lds = (size_t)(TILE_M * (Kp + LDS_PAD) + TILE_M * (CH_N + LDS_PAD)) * sizeof(float);
     LinearKArgs k2 = ka;
     const long wide = (long)((a.M + TILE_M - 1) / TILE_M) * ((a.N + CH_N - 1) / CH_N) * (ka.nz > 1 ? ka.nz : 1);
-    k2.narrow = (a.ln_w == nullptr && a.N >= 512 && wide <= 64) ? 1 : 0;     // too few 256-column workgroups to matter to 256 CUs
+    k2.narrow = (a.ln_w == nullptr && a.N >= SEEME_NARROW_MIN_N && wide <= SEEME_NARROW_MAX) ? 1 : 0;     // too few 256-column workgroups to fill 256 CUs
     const int cw = k2.narrow ? 64 : CH_N;
     dim3 grid((a.M + TILE_M - 1) / TILE_M, (a.N + cw - 1) / cw, ka.nz > 1 ? ka.nz : 1);
     SEEME_HIP(hipFuncSetAttribute((const void*)k_linear, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
