@@ -407,6 +407,8 @@ def main():
 
     B = args.batch
     S = max(1, args.streams)
+    if S > 1:       # batches in flight side by side: let the sampling kernel's workgroups be dealt to all XCDs (launch_den, den_kernels.hip)
+        os.environ.setdefault("SEEME_DEN_XCDS", "8")
     models = [build_models(dev, args.weights, args.vae) for _ in range(S)]
     vae, den, sch = models[0]
     streams = [torch.cuda.Stream() for _ in range(S)]     # (side streams only: the legacy default stream serialises with all others)

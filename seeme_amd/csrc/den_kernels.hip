@@ -12,6 +12,7 @@
 // workgroups walking it in the same order.  Step-invariant pieces (K/V of the condition tokens,
 // linear-attention keys/values) and batch-invariant pieces (time embedding, K/V of the time token,
 // AdaLN scale/shift) are precomputed into tables by seeme_denoiser_{cond,time}_tables.
+#include <atomic>
 #include "common.hpp"
 #include "api_util.hpp"
 #include "den_layout.h"
@@ -981,6 +982,18 @@ static size_t den_lds_bytes(int MS, int N, bool mfma) {
     return (size_t)(768 + MS * 768 + 2 * (VP_LAYER + STG_TT + MS * N * 1024 + (N > 1 ? 0 : MS * 256)) + XB_FLOATS(mfma, MS) + (mfma ? MS * 1024 : 4 * MS * 768)) * sizeof(float);
 }
 
+// XCD packing is for a launch that has the chip to itself.  Launches on several streams at once (batches in flight side by side)
+// would all pack onto the SAME XCDs -- measured: two streams 12.7 k seqs/s packed vs 13.3 k dealt round-robin, eight graph-replayed
+// streams 13.1 k vs 16.1 k; rotating the XCD set per launch instead costs the single stream its L2 contents (4.58 -> 4.63 ms).
+// So: the first stream this process ever samples on packs, every other stream is dealt round-robin (SEEME_DEN_XCDS overrides).
+static bool den_pack_on_stream(hipStream_t st) {
+    static std::atomic<int> state{0};
+    static hipStream_t first;
+    int expected = 0;
+    if (state.compare_exchange_strong(expected, 1)) { first = st; state.store(2); }
+    while (state.load() != 2) {}
+    return st == first;
+}
 template <typename WT, int MS, int V>
 static int launch_den(const DenKArgs& ka, hipStream_t st) {
     const int chains = (MS == 2 && !ka.s.cfg) ? (ka.s.B + 1) / 2 : ka.s.B;
@@ -996,6 +1009,7 @@ static int launch_den(const DenKArgs& ka, hipStream_t st) {
     k2.chains = chains;
     k2.xcds = want ? want : (chains + 15) / 16;
     if (k2.xcds > 8 || chains > 32 * k2.xcds) k2.xcds = 8;      // one workgroup per CU, 32 CUs per XCD
+    if (!want && !den_pack_on_stream(st)) k2.xcds = 8;
     const int grid = k2.xcds < 8 ? (chains + k2.xcds - 1) / k2.xcds * 8 : chains;
     hipLaunchKernelGGL((k_den_sample<WT, MS, V>), dim3(grid), dim3(DEN_THREADS), lds, st, k2);
     return seeme_check_launch("k_den_sample");

@@ -444,6 +444,7 @@ extern "C" int seeme_denoiser_backward_drop(const SeemeDenoiserWeights* w, const
     if (want < 0) { const char* e = getenv("SEEME_DEN_XCDS"); want = e ? atoi(e) : 0; if (want < 0 || want > 8) want = 0; }
     a.xcds = want ? want : (B + 15) / 16;
     if (a.xcds > 8 || B > 32 * a.xcds) a.xcds = 8;
+    if (!want && !den_pack_on_stream((hipStream_t)stream)) a.xcds = 8;
     const int grid = a.xcds < 8 ? (B + a.xcds - 1) / a.xcds * 8 : B;
     hipLaunchKernelGGL(k_den_bwd, dim3(grid), dim3(DEN_THREADS), 0, (hipStream_t)stream, a);
     return seeme_check_launch("k_den_bwd");
