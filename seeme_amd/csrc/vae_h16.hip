@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
 
 // 32 query rows per workgroup.  The 64-row instantiation (SEEME_LAYER_ROWS=64; Sp <= 256 only: 102 KB of LDS) pulls half the
 // weight / K / V bytes per row from L2 and measures 1-2 % SLOWER at B = 256 / 512.  Launches of at most
-// SEEME_LAYER_W8_MAX workgroups (default 320: B = 32 at T = 196 is 224) run their 32 rows on 8 waves instead of 4.
+// SEEME_LAYER_W8_MAX workgroups (default 256 = one per CU: B = 32 at T = 196 is 224) run their 32 rows on 8 waves instead of 4.
 template <int WAVES, int RW>
 static int launch_layer_w(const LayerHArgs& a, hipStream_t st) {
     constexpr int ROWS = RW * WAVES;
@@ -1141,7 +1141,7 @@ static int launch_layer_h(const LayerHArgs& a_in, hipStream_t st) {
     a.Sp = (a.S + CH_N - 1) / CH_N * CH_N;
     static int rows = -1, w8_max = -1;
     if (rows < 0) { const char* e = getenv("SEEME_LAYER_ROWS"); rows = e ? atoi(e) : 32; }
-    if (w8_max < 0) { const char* e = getenv("SEEME_LAYER_W8_MAX"); w8_max = e ? atoi(e) : 320; }
+    if (w8_max < 0) { const char* e = getenv("SEEME_LAYER_W8_MAX"); w8_max = e ? atoi(e) : 256; }
     if (rows == 64 && a.Sp <= 256 && a.q_rows > 32) return launch_layer_w<8, 8>(a, st);
     const long wgs = (long)a.B * ((a.q_rows + 31) / 32);
     return wgs <= w8_max ? launch_layer_w<8, 4>(a, st) : launch_layer_w<4, 8>(a, st);
