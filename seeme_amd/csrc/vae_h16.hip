@@ -812,6 +812,8 @@ struct LayerHArgs {
     const uint4* w1; const float* b1; const uint4* w2; const float* b2; const float* n2_w; const float* n2_b;
     const float* fin_w; const float* fin_b;
     float* out; int out_mode, B;
+    int in_shared;     // 1: q, kp, vp and res are ONE sequence's, the same for every batch member (the decoder's first layer: its
+                       // queries are zeros + positional rows, mld_vae.py:213-222 -- nothing in them depends on the sample)
     const uint4* skip_w; const float* skip_b; const float* skip_src; float* xnext;
     const uint4* qkv_w; const float* qkv_b; unsigned short* q_out; uint4* kp_out; uint4* vp_out;
     const uint4* proj_w; const float* proj_b; float* feats; int F;
@@ -908,6 +910,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     }
     const int q0 = qt * ROWS;
     const size_t base = (size_t)b * a.S;
+    const size_t bin = a.in_shared ? 0 : (size_t)b, base_in = bin * a.S;      // batch member whose inputs this sequence reads
     const int n_valid_keys = min(a.S, a.n_prefix + a.lengths[b]);
     const BiasRegs<NTL> bias_o = bias_load<NTL>(a.bo, wave * CW, 256);
     BRing<NTL, PFA> ring_o;
@@ -918,7 +921,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
 #pragma unroll
         for (int it = 0; it < RW / 2; ++it) {
             const int idx = tid + it * NT, row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
-            qv[it] = *reinterpret_cast<const uint4*>(a.q + (base + (s < a.q_rows ? s : 0)) * 256 + c8);
+            qv[it] = *reinterpret_cast<const uint4*>(a.q + (base_in + (s < a.q_rows ? s : 0)) * 256 + c8);
             if (s >= a.q_rows) qv[it] = make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
     __syncthreads();
     LAYER_DBG(1);
     const int NT16 = (a.S + 15) >> 4;
-    const uint4* Kp = a.kp + (size_t)b * NT16 * 512;
+    const uint4* Kp = a.kp + bin * NT16 * 512;
     for (int c0 = 0; c0 < a.Sp; c0 += CH_N) {
         const int n0 = c0 + wave * CW;
         f32x4 acc[MTL][NTL];
@@ -956,7 +959,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
         f32x4 acc[MTL][NTL];
         acc_zero(acc);
         const int K32 = (n_valid_keys + 31) >> 5;
-        gemm_packed<MTL, NTL, PFK>(Ph, ldph, a.vp + (size_t)b * 16 * (a.spv >> 5) * 64, a.spv >> 5, wave * NTL, 16, K32, acc);
+        gemm_packed<MTL, NTL, PFK>(Ph, ldph, a.vp + bin * 16 * (a.spv >> 5) * 64, a.spv >> 5, wave * NTL, 16, K32, acc);
         acc_store_h16<MTL, NTL>(acc, Qh, ldq, wave * CW, nullptr, SEEME_ACT_NONE);
     }
     __syncthreads();
@@ -992,7 +995,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? LAYER_WPE : 1) void k_laye
 #pragma unroll
         for (int rr = 0; rr < RW; ++rr) {
             const int s = q0 + wave * RW + rr;
-            xr[rr] = *reinterpret_cast<const float4*>(a.res + (base + (s < a.q_rows ? s : 0)) * 256 + lane * 4);
+            xr[rr] = *reinterpret_cast<const float4*>(a.res + (base_in + (s < a.q_rows ? s : 0)) * 256 + lane * 4);
         }
         __builtin_amdgcn_sched_barrier(0);
         LAYER_DBG(16);
@@ -1413,11 +1416,13 @@ int seeme_vae_decode_h16(const SeemeVaeWeights* w, const float* z, const int32_t
     if ((rc = lin_h(st, z, 256, H->ca_fold_w, 256, CL, w->ca_fold_b, ws.cvec, CL, B))) return rc;
     {
         ProHArgs p{};
-        p.mode = 2; p.B = B; p.S = S; p.T = T; p.F = F; p.spv = ws.spv; p.pe = w->pe_dec; p.x = ws.x;
+        // the decoder's first-layer rows and their q | K | V do not depend on the sample: ONE sequence's worth, read by every batch member
+        p.mode = 2; p.B = 1; p.S = S; p.T = T; p.F = F; p.spv = ws.spv; p.pe = w->pe_dec; p.x = ws.x;
         p.qkv_w = (const uint4*)H->dec[0].in_w; p.qkv_b = Dk.layer[0].in_b; p.q_out = kv[0].q; p.kp_out = kv[0].kp; p.vp_out = kv[0].vp;
         if ((rc = launch_pro_h(p, st))) return rc;
     }
     LayerHArgs a = layer_args(Dk.layer[0], H->dec[0], kv[0], ws.x, lengths, B, S, ws.spv, 0, S, ws.cvec + 0 * 256, CL);
+    a.in_shared = 1;
     a.out = ws.sk0; tail_qkv(a, Dk.layer[1], H->dec[1], kv[1]);
     if ((rc = launch_layer_h(a, st))) return rc;
     a = layer_args(Dk.layer[1], H->dec[1], kv[1], ws.sk0, lengths, B, S, ws.spv, 0, S, ws.cvec + 1 * 256, CL);
