@@ -171,6 +171,9 @@ __global__ __launch_bounds__(P2_NT, 2) void k_pn_block2(const PnBlock2Args a) {
     p2_s16x4 pfr[2];
     float pxyz[FIRST ? 2 : 1][3];
     auto tile_rsrc = [&](int tn) {           // buffer over the tile's 16-point groups that hold valid rows (the rest reads as zeros)
+#ifdef P2_ABL_XSAME                          // timing-only ablation: every tile reads the activations of tile 0 (L2-resident; wrong results)
+        tn = 0;
+#endif
         const int sc = tn / a.tiles_x, q0 = (tn - sc * a.tiles_x) * P2_MT, rv = min(P2_MT, a.P - q0);
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x + ((size_t)sc * a.Ppad + q0) * P2_H), 0,
                                                  ((rv + 15) / 16) * 16 * P2_H * 2, 0x00020000);
