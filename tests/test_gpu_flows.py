@@ -571,3 +571,25 @@ def test_launch_mapping_knobs_do_not_change_results(dev, tmp_path):
     for tag, o in outs.items():
         for k in ref:
             assert torch.equal(o[k], ref[k]), (tag, k, float((o[k] - ref[k]).abs().max()))
+
+
+@pytest.mark.parametrize("mode_args,metric_word", [([], "sampled"), (["--mode", "train", "--batch", "8"], "training")])
+def test_bench_two_ranks_rehearsal_on_one_gpu(dev, mode_args, metric_word):
+    """`python bench.py --gpus 2` with no launcher in the environment: bench.py starts the two ranks itself (before any GPU call),
+    they rendezvous on 127.0.0.1, time the steps between barriers, take the max over ranks and rank 0 prints ONE line with
+    n_gpus = 2 and the whole-job value.  On a one-GPU box the ranks share the card over gloo (SEEME_BENCH_BACKEND / _DEVICE);
+    with one rank per GPU the same code runs on RCCL.  Training mode: the flat gradient bucket goes through one all-reduce."""
+    import json
+    import subprocess
+    import sys
+    env = {**os.environ, "SEEME_BENCH_BACKEND": "gloo", "SEEME_BENCH_DEVICE": "0"}
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-parity-check"] + mode_args
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["collective_backend"] == "gloo" and d["scaling"] == "weak"
+    assert metric_word in d["metric"] and d["value"] > 0 and d["steps"] == 2
