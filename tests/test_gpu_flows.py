@@ -561,7 +561,7 @@ def test_launch_mapping_knobs_do_not_change_results(dev, tmp_path):
     probe = os.path.join(REPO, "scripts", "launch_knobs_probe.py")
     outs = {}
     for tag, env in (("default", {}), ("xcds1", {"SEEME_DEN_XCDS": "1"}), ("xcds5", {"SEEME_DEN_XCDS": "5"}), ("xcds8", {"SEEME_DEN_XCDS": "8"}),
-                     ("rows64", {"SEEME_LAYER_ROWS": "64"}), ("waves4", {"SEEME_LAYER_W8_MAX": "0"})):
+                     ("rows64", {"SEEME_LAYER_ROWS": "64"}), ("waves4", {"SEEME_LAYER_W8_MAX": "0"}), ("unfused", {"SEEME_VAE_FUSED": "0"})):
         f = str(tmp_path / (tag + ".pt"))
         r = subprocess.run([sys.executable, probe, f, "37"], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
         assert r.returncode == 0, (tag, r.stderr[-2000:])
@@ -570,6 +570,10 @@ def test_launch_mapping_knobs_do_not_change_results(dev, tmp_path):
     assert all(torch.isfinite(v).all() for v in ref.values())
     for tag, o in outs.items():
         for k in ref:
+            if tag == "unfused":      # the three-kernels-per-layer sequence is an independent implementation of the same fp16 path
+                if k != "latent":     # (row-major K / V, per-sample first decoder layer): equal to fp16 rounding, not bit for bit
+                    assert float((o[k] - ref[k]).abs().max()) < 1e-2 * max(1.0, float(ref[k].abs().max())), (tag, k)
+                continue
             assert torch.equal(o[k], ref[k]), (tag, k, float((o[k] - ref[k]).abs().max()))
 
 
