@@ -209,6 +209,31 @@ typedef struct {
 
 int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeSampleArgs* a, void* stream);
 
+/* ---- the same loop with ONE SAMPLE SPLIT OVER C WORKGROUPS (csrc/den_cluster.inc.hip; MLD._diffusion_reverse, mld.py:467-497, at
+ * batch sizes that leave most of the chip idle: B x C <= 256).  One attention head, one condition token (catab), no CFG.
+ *   wgc : the cluster weight image [layer 5][CU C][unit][wave 8][load][lane 64][16 B], packed by the host
+ *         (seeme_amd/mld_denoiser.py, geometry from seeme_den_cluster_layout); the skip linears of layers 3, 4 are folded
+ *         into that layer's in_proj;
+ *   vpc : the vector array of seeme_den_layout() order with in_b of layers 3, 4 = W_in' b_skip + b_in';
+ *   xchg: exchange workspace (>= seeme_den_cluster_xchg_bytes(B, C), 16-byte aligned), zeroed by the call on `stream`.  Word 0
+ *         of it is non-zero after the launch if a cluster gave up waiting for a peer (results invalid), word 1 counts the
+ *         clusters that ran with L2-local granule stores.
+ *   placement 0: the workgroups of a cluster have equal blockIdx % 8 (one XCD under round-robin dispatch), 1: consecutive
+ *   blockIdx.  flags bit 0: granule stores always write-through.  Placement and flags change speed, never results. */
+typedef struct {
+    const void*  wgc;  int wdtype;       /* 0 = fp32, 1 = bf16, 2 = fp16 */
+    const float* vpc;
+    int C;                               /* workgroups (CUs) per sample: 2, 4 or 8 */
+    int placement;
+    int flags;
+    void* xchg; size_t xchg_bytes;
+} SeemeDenCluster;
+size_t seeme_den_cluster_xchg_bytes(int B, int C);
+/* out[0] units per (layer, CU), [1] bytes per unit, [2] image bytes, [3] wave-loads per unit, [4] k per wave-load,
+ * [5..11] first unit of stage A (x half), A (skip half), B, C, D, E, F */
+int seeme_den_cluster_layout(int C, int wdtype, int64_t* out, int cap);
+int seeme_denoiser_sample_cluster(const SeemeDenoiserWeights* w, const SeemeDenCluster* cl, const SeemeSampleArgs* a, void* stream);
+
 /* ---- stage-2 training (MLD._diffusion_process, mld.py:582-631, and the backward of MldDenoiser.forward) ----
  * Forward = seeme_denoiser_sample with steps 1, SCHED_NONE, per-sample rows, force_query 1 and `save` set, on the
  * unfolded fp32 image.  seeme_den_train_pack refreshes that image, its transposed twin and the vector array from the

@@ -87,6 +87,11 @@ class SampleArgs(C.Structure):
                 ("trow_per_sample", C.c_int), ("coef", fp), ("noise", fp), ("out", fp), ("catab", fp), ("save", fp), ("force_query", C.c_int), ("drop", fp), ("drop_scale", C.c_float)]
 
 
+class DenCluster(C.Structure):
+    _fields_ = [("wgc", fp), ("wdtype", C.c_int), ("vpc", fp), ("C", C.c_int), ("placement", C.c_int), ("flags", C.c_int),
+                ("xchg", fp), ("xchg_bytes", C.c_size_t)]
+
+
 class SmplModel(C.Structure):
     _fields_ = [("V", C.c_int), ("v_template", fp), ("blend_w", fp), ("lbs_weights", fp), ("J_template", fp),
                 ("J_shapedirs", fp), ("parents", fp), ("ex_template", fp), ("ex_shapedirs", fp),
@@ -165,6 +170,9 @@ _SIGNATURES = {
     "seeme_denoiser_cond_tables": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
     "seeme_denoiser_ca_tables": (C.c_int, [C.POINTER(DenoiserWeights), fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
     "seeme_denoiser_sample": (C.c_int, [C.POINTER(DenoiserWeights), C.POINTER(SampleArgs), fp]),
+    "seeme_denoiser_sample_cluster": (C.c_int, [C.POINTER(DenoiserWeights), C.POINTER(DenCluster), C.POINTER(SampleArgs), fp]),
+    "seeme_den_cluster_xchg_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "seeme_den_cluster_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "seeme_den_train_layout": (C.c_int, [C.POINTER(C.c_int64), C.c_int]),
     "seeme_den_train_pack": (C.c_int, [fp, fp, fp, fp, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.c_int, fp, fp]),
     "seeme_denoiser_backward": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp]),

@@ -1,0 +1,609 @@
+// den_cluster.inc.hip -- the sampling loop with ONE SAMPLE SPLIT OVER C WORKGROUPS (CUs)  (included by den_kernels.hip).
+//
+// Reference: the same chain as k_den_sample -- MldDenoiser.forward (mld_denoiser.py:151-244) with
+// LinearTemporalDiffusionTransformerDecoderLayer (mdiff_transformer.py:286-304) inside SkipTransformerEncoder
+// (cross_attention.py:67-83), driven by MLD._diffusion_reverse (mld.py:467-497).
+//
+// Why: at B = 32 (BASELINE configs[1]) k_den_sample keeps 32 of 256 CUs busy and each of them is bound by the 118 GB/s of
+// one CU's vector-memory path (84 us per step for the 9 MB image).  Here a "cluster" of C = 2, 4 or 8 workgroups (one per CU)
+// owns a sample: the three big matrices of a layer are split between them, the small ones are replicated, and a step needs
+// TWO exchanges per layer:
+//
+//   A   in_proj' (q | k | W_o v [| y = skip linear, folded: layers 3, 4])  COLUMN-split by dims: CU c computes dims
+//       c S .. c S + S - 1 (S = 256 / C) of q, k, v' (and y) from the full input vector (replicated)
+//   X1  every CU publishes v'[S] (, y[S]) and its partial scores q.k over its dims (self, condition, time token); every CU
+//       gathers them -> softmax over the 2 + N tokens, attention output, + residual, norm1: replicated, bit-identical
+//   B   linear1 COLUMN-split (1024 / C hidden units per CU), ReLU                      -- no exchange
+//   C   linear2 ROW-split over the CU's hidden units -> 256 partial sums per CU
+//   X2  all-reduce of the 256 partial sums (fixed order of addition) -> + bias, residual, norm2, + ca_block term: replicated
+//   D E F  ffn.linear1 / linear2 / proj_out (64 + 64 + 128 KB at 16 bit) REPLICATED on every CU -- no exchange
+//
+// The skip linears of layers 3 and 4 are folded into that layer's in_proj' on the host ([W_in' W_s ; W_s] acting on
+// cat[x, skip], seeme_amd/mld_denoiser.py): no extra exchange.  One attention head, one condition token (the ca_block term
+// comes from seeme_denoiser_ca_tables), no CFG: the configuration BASELINE's headline names; everything else stays on
+// k_den_sample.
+//
+// Exchange = cdna_hip_programming.md Guideline 16, R2: every value travels as one aligned 8-byte {tag = epoch, value}
+// granule written by ONE store; the epilogue wave of every CU re-reads its granules with sc1 loads (bypass L1) until every
+// tag equals the epoch.  The epoch counts exchanges within the launch (never 0); the host zeroes the granule buffer before
+// every launch.  X1 and X2 alternate, so a buffer is only rewritten after every reader has passed the exchange in between.
+// Stores are write-through (sc1: visible to any CU of the chip) unless the cluster has established in its first exchange
+// (which is always write-through) that all its workgroups report the same XCC id: then plain stores, which stay in that
+// XCD's L2 where the peers' sc1 loads find them (probes/xchg_test.hip: 1.25 us instead of 2.0 us per exchange at C = 8).
+// Correctness never depends on placement; speed does (blockIdx b and b + 8 share an XCD under round-robin dispatch).
+// Every spin is bounded: a cluster that gives up sets a word of the exchange buffer's header and finishes without waiting.
+//
+// Weights: `units` of 8 waves x UL wave-loads x 1 KiB in order of use ([layer][CU][unit][wave][load][lane][16 B]); a wave-load
+// is the MFMA B operand of one (16-output tile, k-block) pair.  A ring of RU units in registers runs RU units (half a layer)
+// ahead of the consumer, across stage, layer and step boundaries.
+
+#define DCL_MAGIC_EPOCH 0x7fffffffu
+#define DCL_SPIN_LIMIT (1u << 22)
+
+typedef __attribute__((address_space(1))) unsigned long long dcl_gu64;
+
+template <typename WT> struct ClW {
+    static constexpr int KL = WT::MFMA ? 32 : 16;      // k per wave-load (16-bit: v_mfma_f32_16x16x32; fp32: 4 x v_mfma_f32_16x16x4)
+    static constexpr int UL = 256 / KL;                // wave-loads per unit
+    static constexpr int RU = WT::MFMA ? 4 : 2;        // units in the register ring (32 x 16 B per lane either way)
+    static constexpr unsigned UNIT_BYTES = 8u * UL * 1024u;
+};
+template <int C> struct ClG {
+    static constexpr int S = 256 / C;                  // dims of q / k / v' / y per CU
+    static constexpr int NB = 1024 / C;                // hidden units of the sa_block MLP per CU
+    static constexpr int TA = S / 32;                  // tiles per wave in stage A (waves 0,1: q; 2,3: k; 4,5: v'; 6,7: y) = units per k-half
+    static constexpr int TB = 8 / C;                   // tiles per wave in stage B = units of stage B = units of stage C
+    static constexpr int U_A = 0, U_AS = TA, U_B = 2 * TA, U_C = U_B + TB, U_D = U_C + TB, U_E = U_D + 1, U_F = U_E + 1, NU = U_F + 2;
+    static constexpr int X1_G = 2 * S + 4;             // granules a CU publishes in X1: v'[S] | y[S] | partial scores [4]
+    // granules per sample: boot [16] | X1 [C][X1_G] | X2 [C][256]
+    static constexpr int G_BOOT = 0, G_X1 = 16, G_X2 = G_X1 + C * X1_G, G_TOTAL = G_X2 + C * 256;
+};
+#define DCL_HDR_BYTES 256   // header of the exchange buffer: [0] give-up code, [1] clusters that used L2-local stores
+
+template <typename WT> struct ClRing { u32x4 r[ClW<WT>::RU][ClW<WT>::UL]; };
+
+struct ClArgs {
+    const void* wgc; unsigned wgc_bytes; const float* vp;
+    DenLayout lay;
+    SeemeSampleArgs s;
+    unsigned long long* xg;      // granules (behind the header)
+    unsigned* hdr;
+    int placement, flags, clusters;
+};
+
+// ---- one unit of the weight stream -> its ring slot
+template <typename WT, int C, int U>
+__device__ __forceinline__ void cl_issue(ClRing<WT>& ring, int wave, unsigned voff, __amdgpu_buffer_rsrc_t rsrc,
+                                         unsigned base_cur, unsigned base_next, bool skip_cur, bool skip_next) {
+    typedef ClW<WT> W; typedef ClG<C> G;
+    constexpr int UU = U % G::NU;
+    constexpr bool NXT = U >= G::NU;
+    static_assert(U < 2 * G::NU && G::NU % W::RU == 0, "ring positions must repeat per layer");
+    const bool sk = NXT ? skip_next : skip_cur;
+    if constexpr (UU < G::U_B) {                       // stage A: the skip half only where the layer has a skip linear; the y waves likewise
+        if constexpr (UU >= G::U_AS) { if (!sk) return; }
+        if (wave >= 6 && !sk) return;
+    }
+    const unsigned soff = (NXT ? base_next : base_cur) + (unsigned)UU * W::UNIT_BYTES;
+#pragma unroll
+    for (int i = 0; i < W::UL; ++i) ring.r[UU % W::RU][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + (unsigned)(i * 1024), 0);
+}
+
+// ---- GEMV input vectors in LDS.  16-bit weights: MFMA A-operand fragments [k-block][k-group 4][row 4][8 halves], row p =
+// part p of the fp32 value (put_x); fp32 weights: the plain fp32 vector.
+struct ClX { const char* base; int foff; };
+template <typename WT>
+__device__ __forceinline__ ClX cl_xin(const float* buf, int lane) {
+    ClX x; x.base = reinterpret_cast<const char*>(buf);
+    x.foff = WT::MFMA ? ((lane >> 4) * 4 + ((lane & 15) & 3)) * 16 : (lane >> 4) * 16;
+    return x;
+}
+template <typename WT>
+__device__ __forceinline__ void cl_put1(float* buf, int k, float v) {     // one element (an MFMA output lane)
+    if constexpr (!WT::MFMA) { buf[k] = v; }
+    else {
+        char* dst = reinterpret_cast<char*>(buf) + (((k >> 5) * 4 + ((k >> 3) & 3)) * 4) * 16 + (k & 7) * 2;
+        if constexpr (WT::HALF) {
+            const _Float16 hi = (_Float16)v;
+            *reinterpret_cast<_Float16*>(dst) = hi;
+            *reinterpret_cast<_Float16*>(dst + 16) = (_Float16)((v - (float)hi) * DEN_F16_LO_SCALE);
+        } else {
+            const __bf16 hi = (__bf16)v; const float r1 = v - (float)hi; const __bf16 mid = (__bf16)r1;
+            *reinterpret_cast<__bf16*>(dst) = hi;
+            *reinterpret_cast<__bf16*>(dst + 16) = mid;
+            *reinterpret_cast<__bf16*>(dst + 32) = (__bf16)(r1 - (float)mid);
+        }
+    }
+}
+// value of the lane's output column from an accumulator (every 16-lane group holds the same 16 columns)
+template <typename WT>
+__device__ __forceinline__ float cl_out(const f32x4& a) {
+    if constexpr (!WT::MFMA) return a.x;
+    else if constexpr (WT::HALF) return fmaf(a.y, 1.f / DEN_F16_LO_SCALE, a.x);
+    else return a.x + (a.y + a.z);
+}
+
+// ---- consume one unit: load i of the unit is load J0 + i of the stage; stage load j = (k-block j / TPW, tile j % TPW)
+template <typename WT, int TPW, int J0, int KBOFF>
+__device__ __forceinline__ void cl_consume(const u32x4 (&slot)[ClW<WT>::UL], const ClX& x, f32x4 (&acc)[TPW]) {
+    typedef ClW<WT> W;
+    uint4 a4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int i = 0; i < W::UL; ++i) {
+        constexpr int dummy = 0; (void)dummy;
+        const int j = J0 + i, kb = j / TPW - KBOFF, t = j % TPW;
+        if constexpr (WT::MFMA) {
+            if (i == 0 || t == 0) a4 = *reinterpret_cast<const uint4*>(x.base + x.foff + kb * 256);
+            if constexpr (WT::HALF) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a4), __builtin_bit_cast(h16x8, slot[i]), acc[t], 0, 0, 0);
+            else acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a4), __builtin_bit_cast(bf16x8, slot[i]), acc[t], 0, 0, 0);
+        } else {
+            if (i == 0 || t == 0) a4 = *reinterpret_cast<const uint4*>(x.base + x.foff + kb * 64);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a4.x), __uint_as_float(slot[i].x), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a4.y), __uint_as_float(slot[i].y), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a4.z), __uint_as_float(slot[i].z), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a4.w), __uint_as_float(slot[i].w), acc[t], 0, 0, 0);
+        }
+    }
+}
+template <int TPW>
+__device__ __forceinline__ void cl_pin(f32x4 (&acc)[TPW]) {   // program-order pin (see Acc::pin)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) asm volatile("" : "+v"(acc[t]) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int TPW>
+__device__ __forceinline__ void cl_zero(f32x4 (&acc)[TPW]) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+// NUN consecutive units of one stage from unit U0 on: consume, then re-fill the freed slot with unit U + RU -- inline for the
+// first NINL units of the call only.  Stages that end in an exchange (A, C) leave the re-fills of their LAST (up to RU) units
+// to cl_refills, after the exchange: loads queued in this CU's vector-memory path right before the publish / poll are latency
+// on the exchange (the hand-off's price sits in the consumer CU's own memory queue, MI355X_MICROARCH.md handoff-1to1).  Units
+// further than RU from the end of such a stage must re-fill inline: their targets are consumed inside the same stage.
+template <typename WT, int C, int U0, int NUN, int TPW, int UI0, int KBOFF, int NINL, int... Is>
+__device__ __forceinline__ void cl_units(ClRing<WT>& ring, const ClX& x, f32x4 (&acc)[TPW], bool active, int wave, unsigned voff,
+                                         __amdgpu_buffer_rsrc_t rsrc, unsigned bc, unsigned bn, bool sc, bool sn, std::integer_sequence<int, Is...>) {
+    typedef ClW<WT> W;
+    (([&] {
+        constexpr int U = U0 + Is;
+        if (active) { cl_consume<WT, TPW, (UI0 + Is) * W::UL, KBOFF>(ring.r[U % W::RU], x, acc); }
+        cl_pin<TPW>(acc);
+        if constexpr (Is < NINL) {
+            cl_issue<WT, C, U + W::RU>(ring, wave, voff, rsrc, bc, bn, sc, sn);
+            cl_pin<TPW>(acc);
+        }
+    }()), ...);
+}
+template <typename WT, int C, int U0, int... Is>
+__device__ __forceinline__ void cl_refills(ClRing<WT>& ring, int wave, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned bc, unsigned bn,
+                                           bool sc, bool sn, std::integer_sequence<int, Is...>) {
+    (cl_issue<WT, C, U0 + Is + ClW<WT>::RU>(ring, wave, voff, rsrc, bc, bn, sc, sn), ...);
+    __builtin_amdgcn_sched_barrier(0);
+}
+constexpr int cl_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- granules
+__device__ __forceinline__ void cl_store_granule(unsigned long long* g, unsigned epoch, float v, bool local) {
+    const unsigned long long x = ((unsigned long long)epoch << 32) | __float_as_uint(v);
+    if (local) *(volatile dcl_gu64*)g = x;                                                       // stays in this XCD's L2
+    else __hip_atomic_store((dcl_gu64*)g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // sc1: write-through
+}
+__device__ __forceinline__ bool cl_tags_ok(const u32x4& a, unsigned epoch) { return (a.y == epoch) & (a.w == epoch); }
+
+template <typename WT, int C>
+__global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef ClW<WT> W; typedef ClG<C> G;
+    // re-fills left until after the exchange: the last RU units of stage A (x half + skip half) and of stage C
+    constexpr int A_DEF0 = cl_clamp(2 * G::TA - W::RU, 0, 2 * G::TA);          // first deferred unit of the 2 TA units of stage A
+    constexpr int A_INL0 = cl_clamp(A_DEF0, 0, G::TA), A_INL1 = cl_clamp(A_DEF0 - G::TA, 0, G::TA), C_INL = cl_clamp(G::TB - W::RU, 0, G::TB);
+    const SeemeSampleArgs& A = ka.s;
+    const DenLayout* __restrict__ lay = &ka.lay;
+    const float* __restrict__ vp = ka.vp;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // which sample, which part of it: placement 0 = the cluster's workgroups have equal blockIdx % 8 (one XCD under
+    // round-robin dispatch), placement 1 = consecutive blockIdx (C different XCDs).  Speed only.
+    int b, c;
+    if (ka.placement == 0) { const int x = blockIdx.x & 7, j = blockIdx.x >> 3; b = x * (ka.clusters / 8) + j / C; c = j % C; }
+    else { b = blockIdx.x / C; c = blockIdx.x % C; }
+    if (b >= A.B) return;                                      // (whole clusters: every member sees the same b)
+    const bool epi = wave == 0;
+    const int N = 1;
+    const int stg_sz = VP_LAYER + STG_TT + N * 1024 + 256;
+    const int ca_R = A.trow_per_sample ? 1 : A.steps;
+
+    float* CONSTV = smem;                        // [768]  query_pos.pe[0], encoder.norm.{weight,bias}
+    float* KEEP = CONSTV + 768;                  // [256]  the latent (epilogue wave)
+    float* STG = KEEP + 256;                     // [2][stg_sz] per-layer operands, double-buffered (stage_dma)
+    float* XA = STG + 2 * stg_sz;                // [512]  GEMV input: layer input x / x2   (16-bit: fragments of 256 k = 2 KiB)
+    float* XB = XA + 512;                        // [512]  GEMV input: x1 / u
+    float* XH = XB + 512;                        // [2 NB] GEMV input: this CU's hidden units / ffn hidden (fragments of NB k)
+    float* SKF = XH + 2 * (G::NB > 128 ? G::NB : 128);   // [2][512] outputs of layers 0, 1 (skip inputs of layers 4, 3)
+    float* QS = SKF + 1024;                      // [S] q, [S] k of this CU's dims
+    float* KS = QS + G::S;
+    float* PART = KS + G::S;                     // [256]
+    float* RES = PART + 256;                     // [256]  the fp32 residual stream
+    int* FLG = reinterpret_cast<int*>(RES + 256);   // [4]
+    constexpr int XZERO = 512 + 512 + 2 * (G::NB > 128 ? G::NB : 128) + 1024;
+
+    const __amdgpu_buffer_rsrc_t wg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ka.wgc), 0, (int)ka.wgc_bytes, 0x00020000);
+    unsigned long long* const xg = ka.xg + (size_t)b * G::G_TOTAL;
+    const __amdgpu_buffer_rsrc_t xr_ = __builtin_amdgcn_make_buffer_rsrc(xg, 0, G::G_TOTAL * 8, 0x00020000);
+    const unsigned voff = (unsigned)wave * (unsigned)(W::UL * 1024) + (unsigned)lane * 16u;
+    const int col = lane & 15;
+    const ClX xa = cl_xin<WT>(XA, lane), xb = cl_xin<WT>(XB, lane), xh = cl_xin<WT>(XH, lane);
+    const float sa_scale = 1.f / 16.f;           // one head of 256 dims
+    if (epi) __builtin_amdgcn_s_setprio(3);
+
+    typedef const __attribute__((address_space(4))) int32_t* CI32;
+    typedef const __attribute__((address_space(4))) float* CF32;
+    const CI32 trow_c = (CI32)(uintptr_t)A.trow;
+    const CF32 coef_c = (CF32)(uintptr_t)A.coef;
+    int row = A.trow_per_sample ? trow_c[b] : trow_c[0];
+
+    // ---- prologue: constants, layer 0 operands, zeroed fragment buffers, first input, first RU units, the XCC census
+    float4 xr = ld4(A.latents + (size_t)b * 256 + 4 * lane);
+    for (int i = tid; i < 192; i += DEN_THREADS)
+        st4(CONSTV + 4 * i, i < 64 ? ld4(vp + lay->pe0 + 4 * i) : (i < 128 ? ld4(vp + lay->fnw + 4 * (i - 64)) : ld4(vp + lay->fnb + 4 * (i - 128))));
+    stage_dma<1, false, 0, 0>(wave, lane, STG, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b, N, 0, ca_R);
+    for (int i = tid; i < XZERO / 4; i += DEN_THREADS) st4(XA + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+    bool dead = false, local = false;
+    if (epi) {
+        // first exchange, always write-through: the XCC id of every workgroup of the cluster (HW_REG_XCC_ID, bits 3:0)
+        const unsigned my_xcc = __builtin_amdgcn_s_getreg(0x1814) & 15u;
+        if (lane == 0) cl_store_granule(xg + G::G_BOOT + c, DCL_MAGIC_EPOCH, __uint_as_float(my_xcc), false);
+        unsigned spins = 0, idv = 0;
+        for (;;) {
+            const unsigned long long x = __hip_atomic_load((dcl_gu64*)(xg + G::G_BOOT + (lane % C)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            idv = (unsigned)x;
+            if (__all((unsigned)(x >> 32) == DCL_MAGIC_EPOCH)) break;
+            if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 1u); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        local = !dead && __all(idv == my_xcc) && !(ka.flags & 1);
+        if (lane == 0) { FLG[0] = local ? 1 : 0; if (local && c == 0) atomicAdd(ka.hdr + 1, 1u); }
+    }
+    wait_vmcnt0();
+    __syncthreads();
+    local = FLG[0] != 0;
+    if (epi) {
+        st4(KEEP + 4 * lane, xr);
+        xr = f4_add(xr, ld4(CONSTV + 4 * lane));                // sample + query_pos (mld_denoiser.py:210)
+        put_x<WT, 1>(XA, 0, 0, lane, xr);
+        st4(RES + 4 * lane, xr);
+    }
+    ClRing<WT> ring;
+    {
+        const unsigned b0 = (unsigned)((0 * C + c) * G::NU) * W::UNIT_BYTES;
+        cl_issue<WT, C, 0>(ring, wave, voff, wg, b0, b0, false, false);
+        cl_issue<WT, C, 1>(ring, wave, voff, wg, b0, b0, false, false);
+        if constexpr (W::RU == 4) { cl_issue<WT, C, 2>(ring, wave, voff, wg, b0, b0, false, false); cl_issue<WT, C, 3>(ring, wave, voff, wg, b0, b0, false, false); }
+    }
+    __syncthreads();
+    int cur = 0;
+
+#pragma unroll 1
+    for (int step = 0; step < A.steps; ++step) {
+        if (step == 2) DEN_DBG(1);
+        if (step == 3) DEN_DBG(2);
+        const int step_next = step + 1 < A.steps ? step + 1 : step;
+        const int row_next = A.trow_per_sample ? row : trow_c[step_next];
+#pragma unroll 1
+        for (int l = 0; l < SEEME_DEN_NL; ++l) {
+            const DenLayerOff* __restrict__ L = &lay->L[l];
+            const int ln = (l + 1 < SEEME_DEN_NL) ? l + 1 : 0;
+            const DenLayerOff* __restrict__ Ln = &lay->L[ln];
+            const bool skip = l >= 3, nskip = ln >= 3;
+            const unsigned bc = (unsigned)((l * C + c) * G::NU) * W::UNIT_BYTES, bn = (unsigned)((ln * C + c) * G::NU) * W::UNIT_BYTES;
+            const float* VP = STG + cur * stg_sz;
+            const float* TTS = VP + VP_LAYER;
+            const float* CT = TTS + STG_TT;
+            const float* CA_ADD = CT + N * 1024;
+            const float* v_skip_b = VP;
+            const float* v_in_b = VP + (L->in_b - L->skip_b);
+            const float* v_n1w = VP + (L->n1w - L->skip_b), *v_n1b = VP + (L->n1b - L->skip_b);
+            const float* v_l1b = VP + (L->l1b - L->skip_b), *v_l2b = VP + (L->l2b - L->skip_b);
+            const float* v_n2w = VP + (L->n2w - L->skip_b), *v_n2b = VP + (L->n2b - L->skip_b);
+            const float* v_f1b = VP + (L->f1b - L->skip_b), *v_f2b = VP + (L->f2b - L->skip_b);
+            const float* v_fsnw = VP + (L->fsnw - L->skip_b), *v_fsnb = VP + (L->fsnb - L->skip_b);
+            const float* v_fo_b = VP + (L->fo_b - L->skip_b);
+            const bool ywave = wave >= 6;
+            const unsigned e1 = 1u + 2u * (unsigned)(step * SEEME_DEN_NL + l), e2 = e1 + 1u;   // epochs of this layer's two exchanges
+
+            // ================= A: in_proj' (+ folded skip linear), column-split by dims =================
+            {
+                f32x4 acc[G::TA];
+                cl_zero<G::TA>(acc);
+                const bool act = skip || !ywave;
+                cl_units<WT, C, G::U_A, G::TA, G::TA, 0, 0, A_INL0>(ring, xa, acc, act, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TA>{});
+                {   // second k-half: the skip input (output of layer 1 for layer 3, of layer 0 for layer 4: xs.pop(), cross_attention.py:77-79)
+                    const ClX xs = cl_xin<WT>(SKF + (l == 3 ? 512 : 0), lane);
+                    cl_units<WT, C, G::U_AS, G::TA, G::TA, G::TA, W::UL, A_INL1>(ring, xs, acc, skip, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TA>{});
+                }
+                if (act && lane < 16) {
+#pragma unroll
+                    for (int t = 0; t < G::TA; ++t) {
+                        const int T = wave * G::TA + t, part = T / (G::S / 16), d = (T % (G::S / 16)) * 16 + col, D = c * G::S + d;
+                        const float val = cl_out<WT>(acc[t]);
+                        const unsigned epoch = e1;
+                        if (part == 0) QS[d] = val + v_in_b[D];
+                        else if (part == 1) KS[d] = val + v_in_b[256 + D];
+                        else if (part == 2) cl_store_granule(xg + G::G_X1 + c * G::X1_G + d, epoch, val + v_in_b[512 + D], local);
+                        else cl_store_granule(xg + G::G_X1 + c * G::X1_G + G::S + d, epoch, val + v_skip_b[D], local);
+                    }
+                }
+            }
+            __syncthreads(); DEN_DBG(0);
+            if (epi) {
+                // partial scores over this CU's dims: token 0 itself, the condition token, the time token (last; mdiff_transformer.py:295)
+                const unsigned epoch = e1;
+                float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+                for (int dd = 0; dd < G::S; dd += 64) {
+                    const int d = dd + lane;
+                    if (d < G::S) {
+                        const float q = QS[d];
+                        p0 = fmaf(q, KS[d], p0); p1 = fmaf(q, CT[c * G::S + d], p1); p2 = fmaf(q, TTS[c * G::S + d], p2);
+                    }
+                }
+                p0 = wave_sum(p0) * sa_scale; p1 = wave_sum(p1) * sa_scale; p2 = wave_sum(p2) * sa_scale;
+                if (lane < 4) cl_store_granule(xg + G::G_X1 + c * G::X1_G + 2 * G::S + lane, epoch, lane == 0 ? p0 : (lane == 1 ? p1 : (lane == 2 ? p2 : 0.f)), local);
+                // ---- X1: gather v' (and y), all-reduce the scores
+                const int pub = (4 * lane) / G::S, off = (4 * lane) % G::S;
+                const unsigned o_v = (unsigned)((G::G_X1 + pub * G::X1_G + off) * 8);
+                const unsigned o_s = (unsigned)((G::G_X1 + (lane % C) * G::X1_G + 2 * G::S) * 8);
+                u32x4 gv0, gv1, gy0, gy1, gs0, gs1;
+                gy0 = gy1 = u32x4{0u, epoch, 0u, epoch};
+                unsigned spins = 0;
+                for (;;) {
+                    gv0 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_v, 0, 16);
+                    gv1 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_v + 16, 0, 16);
+                    if (skip) {
+                        gy0 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_v + G::S * 8, 0, 16);
+                        gy1 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_v + G::S * 8 + 16, 0, 16);
+                    }
+                    gs0 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_s, 0, 16);
+                    gs1 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_s + 16, 0, 16);
+                    const bool ok = cl_tags_ok(gv0, epoch) & cl_tags_ok(gv1, epoch) & cl_tags_ok(gy0, epoch) & cl_tags_ok(gy1, epoch)
+                                  & cl_tags_ok(gs0, epoch) & cl_tags_ok(gs1, epoch);
+                    if (__all(ok) || dead) break;
+                    if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 2u); break; }
+                }
+                DEN_DBG(0);
+                float s0 = __uint_as_float(gs0.x), s1 = __uint_as_float(gs0.z), s2 = __uint_as_float(gs1.x);
+                // sum over the C publishers (aligned groups of C lanes hold one each): butterfly, the same order on every CU
+                if (C >= 2) { s0 += dpp_f(s0, 0); s1 += dpp_f(s1, 0); s2 += dpp_f(s2, 0); }
+                if (C >= 4) { s0 += dpp_f(s0, 1); s1 += dpp_f(s1, 1); s2 += dpp_f(s2, 1); }
+                if (C >= 8) { s0 += dpp_f(s0, 2); s1 += dpp_f(s1, 2); s2 += dpp_f(s2, 2); }
+                const float mx = fmaxf(s0, fmaxf(s1, s2));
+                const float e0 = fast_exp(s0 - mx), e1 = fast_exp(s1 - mx), e2 = fast_exp(s2 - mx);
+                const float inv = fast_rcp(e0 + e1 + e2);
+                const float4 vv = make_float4(__uint_as_float(gv0.x), __uint_as_float(gv0.z), __uint_as_float(gv1.x), __uint_as_float(gv1.z));
+                float4 att = f4_scale(vv, e0 * inv);
+                att = f4_fma(e1 * inv, ld4(CT + 256 + 4 * lane), att);
+                att = f4_fma(e2 * inv, ld4(TTS + 256 + 4 * lane), att);
+                if (skip) xr = make_float4(__uint_as_float(gy0.x), __uint_as_float(gy0.z), __uint_as_float(gy1.x), __uint_as_float(gy1.z));
+                xr = wave_ln(f4_add(xr, att), v_n1w, v_n1b, lane);        // the "values" carry out_proj: residual + norm1
+                put_x<WT, 1>(XB, 0, 0, lane, xr);
+            }
+            __syncthreads(); DEN_DBG(0);
+
+            // ================= B: linear1 + ReLU, column-split =================
+            cl_refills<WT, C, G::U_A + A_DEF0>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2 * G::TA - A_DEF0>{});   // slots of stage A
+            // (the next layer's operands leave for the other half of the staging buffer here: every wave consumes F units,
+            //  requested later than these copies, before the barrier that closes the layer)
+            stage_dma<1, false, 0, 0>(wave, lane, STG + (cur ^ 1) * stg_sz, vp, Ln, A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW, ln, A, b, N,
+                                      A.trow_per_sample ? 0 : (ln == 0 ? step_next : step), ca_R);
+            {
+                f32x4 acc[G::TB];
+                cl_zero<G::TB>(acc);
+                cl_units<WT, C, G::U_B, G::TB, G::TB, 0, 0, G::TB>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB>{});
+                if (lane < 16) {
+#pragma unroll
+                    for (int t = 0; t < G::TB; ++t) {
+                        const int j = (wave * G::TB + t) * 16 + col;
+                        cl_put1<WT>(XH, j, fmaxf(cl_out<WT>(acc[t]) + v_l1b[c * G::NB + j], 0.f));
+                    }
+                }
+            }
+            __syncthreads(); DEN_DBG(0);
+
+            // ================= C: linear2, row-split -> X2 =================
+            {
+                f32x4 acc[2];
+                cl_zero<2>(acc);
+                cl_units<WT, C, G::U_C, G::TB, 2, 0, 0, C_INL>(ring, xh, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB>{});
+                if (lane < 32) {
+                    const float val = (lane & 16) ? cl_out<WT>(acc[1]) : cl_out<WT>(acc[0]);
+                    cl_store_granule(xg + G::G_X2 + c * 256 + (2 * wave + (lane >> 4)) * 16 + col, e2, val, local);
+                }
+            }
+            if (epi) {
+                const unsigned epoch = e2;
+                float4 sum;
+                unsigned spins = 0;
+                for (;;) {
+                    u32x4 g[C][2];
+#pragma unroll
+                    for (int p = 0; p < C; ++p) {
+                        const unsigned o = (unsigned)((G::G_X2 + p * 256 + 4 * lane) * 8);
+                        g[p][0] = __builtin_amdgcn_raw_buffer_load_b128(xr_, o, 0, 16);
+                        g[p][1] = __builtin_amdgcn_raw_buffer_load_b128(xr_, o + 16, 0, 16);
+                    }
+                    bool ok = true;
+                    sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int p = 0; p < C; ++p) {
+                        ok &= cl_tags_ok(g[p][0], epoch) & cl_tags_ok(g[p][1], epoch);
+                        sum.x += __uint_as_float(g[p][0].x); sum.y += __uint_as_float(g[p][0].z);
+                        sum.z += __uint_as_float(g[p][1].x); sum.w += __uint_as_float(g[p][1].z);
+                    }
+                    if (__all(ok) || dead) break;
+                    if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 4u); break; }
+                }
+                DEN_DBG(0);
+                // + bias, residual, norm2; ONE condition token: x + Stylization(v) does not depend on x (seeme_denoiser_ca_tables)
+                xr = wave_ln(f4_add(xr, f4_add(sum, ld4(v_l2b + 4 * lane))), v_n2w, v_n2b, lane);
+                xr = f4_add(xr, ld4(CA_ADD + 4 * lane));
+                put_x<WT, 1>(XA, 0, 0, lane, xr);
+                st4(RES + 4 * lane, xr);
+            }
+            __syncthreads(); DEN_DBG(0);
+
+            // ================= D: ffn.linear1 + GELU (replicated) =================
+            cl_refills<WT, C, G::U_C + C_INL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB - C_INL>{});       // slots of stage C
+            {
+                f32x4 acc[1];
+                cl_zero<1>(acc);
+                cl_units<WT, C, G::U_D, 1, 1, 0, 0, 1>(ring, xa, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
+                if (lane < 16) {
+                    const int j = wave * 16 + col;
+                    cl_put1<WT>(XH, j, fast_gelu(cl_out<WT>(acc[0]) + v_f1b[j]));
+                }
+            }
+            __syncthreads(); DEN_DBG(0);
+            // ================= E: ffn.linear2 -> LayerNorm, AdaLN, SiLU (replicated) =================
+            {
+                f32x4 acc[2];
+                cl_zero<2>(acc);
+                cl_units<WT, C, G::U_E, 1, 2, 0, 0, 1>(ring, xh, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
+                if (lane < 32) PART[(2 * wave + (lane >> 4)) * 16 + col] = (lane & 16) ? cl_out<WT>(acc[1]) : cl_out<WT>(acc[0]);
+            }
+            __syncthreads(); DEN_DBG(0);
+            if (epi) {
+                const float4 y2 = f4_add(ld4(PART + 4 * lane), ld4(v_f2b + 4 * lane));
+                const float4 hh = f4_adaln(wave_ln(y2, v_fsnw, v_fsnb, lane), ld4(TTS + 1024 + 4 * lane), ld4(TTS + 1280 + 4 * lane));
+                put_x<WT, 1>(XB, 0, 0, lane, f4_silu(hh));
+            }
+            __syncthreads(); DEN_DBG(0);
+            // ================= F: ffn.proj_out.out_layers + residual (replicated); writes the next layer's input =================
+            {
+                f32x4 acc[2];
+                cl_zero<2>(acc);
+                cl_units<WT, C, G::U_F, 2, 2, 0, 0, 2>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2>{});
+                if (lane < 32) {
+                    const int n = (2 * wave + (lane >> 4)) * 16 + col;
+                    const float xn = RES[n] + ((lane & 16) ? cl_out<WT>(acc[1]) : cl_out<WT>(acc[0])) + v_fo_b[n];
+                    RES[n] = xn;
+                    cl_put1<WT>(XA, n, xn);
+                    if (l < 2) cl_put1<WT>(SKF + 512 * l, n, xn);                      // xs.append(x) (cross_attention.py:70-72)
+                }
+            }
+            __syncthreads(); DEN_DBG(0);
+            if (l + 1 < SEEME_DEN_NL) {
+                if (epi && !nskip) xr = ld4(RES + 4 * lane);                          // residual of the next layer's attention
+            } else {
+                // ---- stack norm -> model output (cross_attention.py:82-83), scheduler.step (mld.py:495-497)
+                if (epi) {
+                    float4 e = wave_ln(ld4(RES + 4 * lane), CONSTV + 256, CONSTV + 512, lane);
+                    if (A.sched == SEEME_SCHED_NONE) {
+                        st4(KEEP + 4 * lane, e);
+                    } else {
+                        const CF32 cf = coef_c + (size_t)step * 8;
+                        const float c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5], clip = cf[6], ptype = cf[7];
+                        float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (A.noise != nullptr) nz = ld4(A.noise + ((size_t)step * A.B + b) * 256 + 4 * lane);
+                        const float4 lat = ld4(KEEP + 4 * lane);
+                        const float xs[4] = {lat.x, lat.y, lat.z, lat.w}, es4[4] = {e.x, e.y, e.z, e.w}, ns[4] = {nz.x, nz.y, nz.z, nz.w};
+                        float o[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float x0, ep;
+                            if (ptype == 0.f) { ep = es4[i]; x0 = (xs[i] - c1 * ep) / c0; }
+                            else              { x0 = es4[i]; ep = (xs[i] - c0 * x0) / c1; }
+                            if (clip != 0.f) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+                            o[i] = c2 * x0 + c3 * ep + c5 * xs[i] + c4 * ns[i];
+                        }
+                        const float4 nl = make_float4(o[0], o[1], o[2], o[3]);
+                        st4(KEEP + 4 * lane, nl);
+                        xr = f4_add(nl, ld4(CONSTV + 4 * lane));
+                        put_x<WT, 1>(XA, 0, 0, lane, xr);
+                        st4(RES + 4 * lane, xr);
+                    }
+                }
+                __syncthreads(); DEN_DBG(0);
+            }
+            cur ^= 1;
+        }
+        row = row_next;
+    }
+    DEN_DBG(3);
+    if (epi && c == 0) st4(A.out + (size_t)b * 256 + 4 * lane, ld4(KEEP + 4 * lane));
+#pragma unroll
+    for (int s = 0; s < W::RU; ++s) asm volatile("" ::"v"(ring.r[s][0].x));
+}
+
+template <int C>
+static size_t cl_lds_bytes() {
+    typedef ClG<C> G;
+    const int stg_sz = VP_LAYER + STG_TT + 1024 + 256;
+    return (size_t)(768 + 256 + 2 * stg_sz + 512 + 512 + 2 * (G::NB > 128 ? G::NB : 128) + 1024 + 2 * G::S + 256 + 256 + 4) * sizeof(float);
+}
+
+extern "C" size_t seeme_den_cluster_xchg_bytes(int B, int C) {
+    const size_t per = C == 8 ? ClG<8>::G_TOTAL : (C == 4 ? ClG<4>::G_TOTAL : ClG<2>::G_TOTAL);
+    const size_t clusters = (size_t)(B + 7) / 8 * 8;
+    return DCL_HDR_BYTES + clusters * per * 8;
+}
+// out[0] = units per (layer, CU), [1] = bytes per unit, [2] = image bytes, [3] = wave-loads per unit, [4] = k per wave-load,
+// [5..11] = first unit of A (x half), A (skip half), B, C, D, E, F
+extern "C" int seeme_den_cluster_layout(int C, int wdtype, int64_t* out, int cap) {
+    if (cap < 12) return seeme_fail("den_cluster_layout: output too small");
+    if (C != 2 && C != 4 && C != 8) return seeme_fail("den_cluster_layout: C must be 2, 4 or 8");
+    const int TA = 256 / C / 32, TB = 8 / C;
+    const int64_t NU = 2 * TA + 2 * TB + 4, UL = wdtype == 0 ? 16 : 8, UB = 8 * UL * 1024;
+    out[0] = NU; out[1] = UB; out[2] = (int64_t)SEEME_DEN_NL * C * NU * UB; out[3] = UL; out[4] = 256 / UL;
+    out[5] = 0; out[6] = TA; out[7] = 2 * TA; out[8] = 2 * TA + TB; out[9] = 2 * TA + 2 * TB; out[10] = out[9] + 1; out[11] = out[9] + 2;
+    return 0;
+}
+
+template <typename WT, int C>
+static int launch_den_cluster(const ClArgs& ka0, hipStream_t st) {
+    ClArgs ka = ka0;
+    ka.clusters = (ka.s.B + 7) / 8 * 8;
+    const int grid = ka.clusters * C;
+    if (grid > 256) return seeme_fail("denoiser_sample_cluster: B x C exceeds one workgroup per CU (256)");
+    const size_t lds = cl_lds_bytes<C>();
+    if (lds > 160 * 1024 || lds <= 80 * 1024) return seeme_fail("denoiser_sample_cluster: LDS footprint must force one workgroup per CU");
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_den_cluster<WT, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // granules and header are zeroed before EVERY launch (tags of an earlier launch must never match)
+    SEEME_HIP(hipMemsetAsync(ka.hdr, 0, seeme_den_cluster_xchg_bytes(ka.s.B, C), st));
+    hipLaunchKernelGGL((k_den_cluster<WT, C>), dim3(grid), dim3(DEN_THREADS), lds, st, ka);
+    return seeme_check_launch("k_den_cluster");
+}
+template <typename WT>
+static int launch_den_cluster_c(const ClArgs& ka, int C, hipStream_t st) {
+    if (C == 8) return launch_den_cluster<WT, 8>(ka, st);
+    if (C == 4) return launch_den_cluster<WT, 4>(ka, st);
+    if (C == 2) return launch_den_cluster<WT, 2>(ka, st);
+    return seeme_fail("denoiser_sample_cluster: C must be 2, 4 or 8");
+}
+
+extern "C" int seeme_denoiser_sample_cluster(const SeemeDenoiserWeights* w, const SeemeDenCluster* cl, const SeemeSampleArgs* a, void* stream) {
+    if (a->B <= 0) return seeme_fail("denoiser_sample_cluster: B must be > 0");
+    if (a->N != 1 || a->catab == nullptr || a->force_query) return seeme_fail("denoiser_sample_cluster: one condition token with its ca table");
+    if (w->nhead != 1 || !w->sa_fold) return seeme_fail("denoiser_sample_cluster: one attention head (folded out_proj)");
+    if (a->cfg || a->save != nullptr) return seeme_fail("denoiser_sample_cluster: no CFG pair, no training forward");
+    if (w->ff_sa != FF_SA || w->ff != FF_D) return seeme_fail("denoiser_sample_cluster: built for sa ff 1024 / ffn_dim 128");
+    if (a->sched == SEEME_SCHED_NONE && a->steps != 1) return seeme_fail("denoiser_sample_cluster: SCHED_NONE needs steps == 1");
+    if (a->steps < 1) return seeme_fail("denoiser_sample_cluster: steps must be >= 1");
+    if (cl->xchg == nullptr || cl->xchg_bytes < seeme_den_cluster_xchg_bytes(a->B, cl->C)) return seeme_fail("denoiser_sample_cluster: exchange buffer too small");
+    if (((uintptr_t)cl->xchg & 15) != 0) return seeme_fail("denoiser_sample_cluster: exchange buffer must be 16-byte aligned");
+    int64_t lo[12];
+    int rc = seeme_den_cluster_layout(cl->C, cl->wdtype, lo, 12);
+    if (rc) return rc;
+    ClArgs ka;
+    ka.wgc = cl->wgc; ka.wgc_bytes = (unsigned)lo[2]; ka.vp = cl->vpc;
+    ka.lay = seeme_make_den_layout(FF_SA, FF_D);
+    ka.s = *a;
+    ka.hdr = (unsigned*)cl->xchg;
+    ka.xg = (unsigned long long*)((char*)cl->xchg + DCL_HDR_BYTES);
+    ka.placement = cl->placement; ka.flags = cl->flags; ka.clusters = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (cl->wdtype == 0) return launch_den_cluster_c<WF32>(ka, cl->C, st);
+    if (cl->wdtype == 1) return launch_den_cluster_c<WBF16>(ka, cl->C, st);
+    if (cl->wdtype == 2) return launch_den_cluster_c<WF16>(ka, cl->C, st);
+    return seeme_fail("denoiser_sample_cluster: wdtype must be 0 (fp32), 1 (bf16) or 2 (fp16)");
+}

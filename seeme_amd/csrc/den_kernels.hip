@@ -1152,3 +1152,4 @@ extern "C" int seeme_debug_den_times(unsigned long long* host, int n) {
 #endif
 
 #include "den_train.inc.hip"
+#include "den_cluster.inc.hip"

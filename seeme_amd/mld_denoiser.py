@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional
 
 import torch
@@ -40,6 +41,20 @@ def timestep_features(timesteps: torch.Tensor, dim: int = 256, flip_sin_to_cos: 
     if dim % 2 == 1:
         emb = torch.nn.functional.pad(emb, (0, 1, 0, 0))
     return emb
+
+
+def cluster_pack_stage(Wsub: torch.Tensor, TPW: int, KL: int, UL: int) -> torch.Tensor:
+    """One GEMV stage of the cluster weight image (csrc/den_cluster.inc.hip): [8 TPW x 16 outputs, K] -> [units, wave 8, UL, lane 64,
+    KL / 4].  Wave w owns the 16-output tiles w TPW .. w TPW + TPW - 1; its wave-loads run k-block major, tile inner (load j =
+    k-block j // TPW, tile j % TPW), UL loads per unit; lane 16 g + r of a load holds W[16 T + r][KL kb + (KL/4) g .. + KL/4 - 1]:
+    the B operand of v_mfma_f32_16x16x32 (16-bit, KL = 32) or of four v_mfma_f32_16x16x4 (fp32, KL = 16)."""
+    EPL = KL // 4
+    NT, K = Wsub.shape[0] // 16, Wsub.shape[1]
+    assert NT == 8 * TPW and K % KL == 0 and (K // KL * TPW) % UL == 0
+    KB = K // KL
+    t = Wsub.reshape(NT, 16, KB, 4, EPL).permute(0, 2, 3, 1, 4).reshape(8, TPW, KB, 64, EPL)
+    t = t.permute(0, 2, 1, 3, 4).reshape(8, (KB * TPW) // UL, UL, 64, EPL)
+    return t.permute(1, 0, 2, 3, 4)
 
 
 class _TimestepEmbeddingParams(nn.Module):
@@ -113,6 +128,7 @@ class MldDenoiser(nn.Module):
                  text_encoded_dim: int = 256,
                  nclasses: int = 10,
                  weight_dtype: str = "fp32",
+                 cluster="auto",
                  **kwargs) -> None:
         super().__init__()
         self.latent_dim = latent_dim[-1]
@@ -142,6 +158,13 @@ class MldDenoiser(nn.Module):
         if weight_dtype not in ("fp32", "bf16", "fp16"):
             raise ValueError("weight_dtype must be 'fp32', 'bf16' or 'fp16'")
         self.weight_dtype = weight_dtype
+        # CUs per sample in sample_loop / forward: "auto" (8 / 4 / 2 while B x C <= 256, i.e. batches that leave most of the chip
+        # idle; one CU per sample beyond), 0 (never) or 2 / 4 / 8.  SEEME_DEN_CLUSTER overrides.  Speed only.
+        if cluster not in ("auto", 0, 2, 4, 8):
+            raise ValueError("cluster must be 'auto', 0, 2, 4 or 8")
+        self.cluster = cluster
+        self.cluster_placement = 0       # 0: a cluster's workgroups share an XCD (round-robin dispatch), 1: spread over C XCDs
+        self.cluster_flags = 0           # bit 0: write-through granule stores always
 
         d = self.latent_dim
         self.time_embedding = _TimestepEmbeddingParams(text_encoded_dim, d)
@@ -152,6 +175,8 @@ class MldDenoiser(nn.Module):
         self._wcache = None
         self._ws = None
         self._table_cache = {}
+        self._ccache = {}
+        self._xchg = None
 
     # ------------------------------------------------------------------ weight image
     def _layout(self):
@@ -266,9 +291,84 @@ class MldDenoiser(nn.Module):
         w.ca_pn_w, w.ca_pn_b, w.ca_po_w, w.ca_po_b = pn_w.data_ptr(), pn_b.data_ptr(), po_w.data_ptr(), po_b.data_ptr()
         w.sa_fold = int(fold)
         w.ca_fold_w, w.ca_fold_b, w.ln_ones, w.ln_zeros = cf_w.data_ptr(), cf_b.data_ptr(), ones.data_ptr(), zeros.data_ptr()
+        self._ccache = {}
+        self._fold_parts = (in_proj, vp, layers)
         self._wcache = (fpnt, w, (wg, vp, kv_w, kv_b, st_w, st_b, ca_w, ca_b, lay_dev, cf_w, cf_b, ones, zeros, pn_w, pn_b, po_w, po_b))
         self._table_cache = {}
         return w
+
+    # ------------------------------------------------------------------ cluster image (csrc/den_cluster.inc.hip)
+    def _cluster_weights(self, Cc: int):
+        """Weight image for one sample split over Cc CUs: [layer][CU][unit][wave 8][load][lane 64][16 B] in order of use.
+        Stage A = rows c S .. of q | k | W_o v (| y) of [W_in' W_s ; W_s] (layers 3, 4: the skip linear folded in, acting on
+        cat[x, skip]; cross_attention.py:77-79) or of W_in' (layers 0-2); B = linear1 rows of the CU's hidden units; C = the
+        matching columns of linear2; D, E, F = ffn.linear1 / linear2 / proj_out whole (replicated)."""
+        self._weights()
+        if Cc in self._ccache:
+            return self._ccache[Cc]
+        in_proj, vp, layers = self._fold_parts
+        dev = vp.device
+        code = {"fp32": 0, "bf16": 1, "fp16": 2}[self.weight_dtype]
+        wdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[self.weight_dtype]
+        lo = (C.c_int64 * 12)()
+        L.check(L.lib().seeme_den_cluster_layout(Cc, code, lo, 12), "seeme_den_cluster_layout")
+        NU, UB, total, UL, KL = (int(v) for v in lo[:5])
+        EPL = KL // 4                                   # elements per lane per wave-load (16 B)
+        S, NB, TA, TB = 256 // Cc, 1024 // Cc, 256 // Cc // 32, 8 // Cc
+
+        def pack_stage(Wsub, TPW):
+            return cluster_pack_stage(Wsub, TPW, KL, UL)
+
+        blocks = self.encoder.blocks()
+        img = torch.zeros(5, Cc, NU, 8, UL, 64, EPL, dtype=wdt, device=dev)
+        vpc = vp.clone()
+        with torch.no_grad():
+            for l, (blk, o) in enumerate(zip(blocks, layers)):
+                Wq, bq = in_proj[l][0].double(), in_proj[l][1].double()
+                if l >= 3:
+                    Ws = self.encoder.linear_blocks[l - 3].weight.detach().double()
+                    bs = self.encoder.linear_blocks[l - 3].bias.detach().double()
+                    Wa = torch.cat([Wq @ Ws, Ws])                                  # [1024, 512] on cat[x, skip]
+                    vpc[o["in_b"]:o["in_b"] + 768] = (Wq @ bs + bq).float()
+                else:
+                    Wa = torch.cat([Wq, torch.zeros(256, 256, dtype=torch.float64, device=dev)])   # no y rows
+                W1, W2 = blk.sa_block.linear1.weight.detach(), blk.sa_block.linear2.weight.detach()
+                Wf1, Wf2 = blk.ffn.linear1.weight.detach(), blk.ffn.linear2.weight.detach()
+                Wfo = blk.ffn.proj_out.out_layers[2].weight.detach()
+                for c in range(Cc):
+                    rows = torch.cat([torch.arange(p * 256 + c * S, p * 256 + (c + 1) * S, device=dev) for p in range(4)])
+                    ua = pack_stage(Wa[rows].to(wdt), TA)              # TA units (K = 256) or 2 TA (K = 512)
+                    img[l, c, 0:ua.shape[0]] = ua
+                    img[l, c, 2 * TA:2 * TA + TB] = pack_stage(W1[c * NB:(c + 1) * NB].to(wdt), TB)
+                    img[l, c, 2 * TA + TB:2 * TA + 2 * TB] = pack_stage(W2[:, c * NB:(c + 1) * NB].to(wdt), 2)
+                    u0 = 2 * TA + 2 * TB
+                    img[l, c, u0:u0 + 1] = pack_stage(Wf1.to(wdt), 1)
+                    img[l, c, u0 + 1:u0 + 2] = pack_stage(Wf2.to(wdt), 2)
+                    img[l, c, u0 + 2:u0 + 4] = pack_stage(Wfo.to(wdt), 2)
+        assert img.numel() * img.element_size() == total
+        self._ccache[Cc] = (img, vpc, code)
+        return self._ccache[Cc]
+
+    def _cluster_size(self, B: int, N: int, cfg: bool) -> int:
+        """CUs per sample for this launch (0: the one-CU-per-sample kernel)."""
+        want = os.environ.get("SEEME_DEN_CLUSTER")
+        want = self.cluster if want is None else (want if want == "auto" else int(want))
+        if want == 0 or N != 1 or cfg or self.num_heads != 1:
+            return 0
+        Bp = (B + 7) // 8 * 8
+        if want == "auto":
+            for Cc in (8, 4, 2):
+                if Bp * Cc <= 256:
+                    return Cc
+            return 0
+        return want if Bp * want <= 256 else 0
+
+    def cluster_status(self):
+        """(give-up code, clusters that ran with L2-local granule stores) of the last cluster launch; synchronises."""
+        if self._xchg is None:
+            return (0, 0)
+        hdr = self._xchg[:8].cpu().view(torch.int32)
+        return int(hdr[0]), int(hdr[1])
 
     def _workspace(self, rows: int, device):
         need = L.lib().seeme_denoiser_workspace_bytes(rows, 0, 0)
@@ -324,6 +424,20 @@ class MldDenoiser(nn.Module):
         catab = self.ca_tables(ctab, ttab, trow, per_sample) if N == 1 else None
         a.catab = L.ptr(catab)
         w = self._weights()
+        Cc = self._cluster_size(B, N, bool(cfg))
+        if Cc:
+            img, vpc, code = self._cluster_weights(Cc)
+            need = L.lib().seeme_den_cluster_xchg_bytes(B, Cc)
+            if self._xchg is None or self._xchg.numel() < need or self._xchg.device != latents2d.device:
+                self._xchg = torch.zeros(need, dtype=torch.uint8, device=latents2d.device)
+            cl = L.DenCluster()
+            cl.wgc, cl.wdtype, cl.vpc, cl.C = img.data_ptr(), code, vpc.data_ptr(), Cc
+            cl.placement = int(os.environ.get("SEEME_DEN_CLUSTER_PLACE", self.cluster_placement))
+            cl.flags = int(os.environ.get("SEEME_DEN_CLUSTER_FLAGS", self.cluster_flags))
+            cl.xchg, cl.xchg_bytes = self._xchg.data_ptr(), self._xchg.numel()
+            L.check(L.lib().seeme_denoiser_sample_cluster(C.byref(w), C.byref(cl), C.byref(a), L.current_stream()),
+                    "seeme_denoiser_sample_cluster")
+            return out
         L.check(L.lib().seeme_denoiser_sample(C.byref(w), C.byref(a), L.current_stream()), "seeme_denoiser_sample")
         return out
 

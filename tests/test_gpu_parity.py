@@ -908,3 +908,105 @@ def test_smpl_joints_backward_matches_autograd(dev):
     p = pose.clone().requires_grad_(True)                   # without a translation
     smpl_joints_hip(smpl, betas, p, None).mul(wgt).sum().backward()
     assert rel_err(p.grad.cpu().numpy(), res[1][1].cpu().numpy()) < 1e-4
+
+
+# ----------------------------------------------------------------------------- one sample split over C CUs (k_den_cluster)
+def _with_cluster(den, Cc, place=0, flags=0):
+    den.cluster, den.cluster_placement, den.cluster_flags = Cc, place, flags
+    return den
+
+
+@pytest.mark.parametrize("Cc", [8, 4, 2])
+def test_cluster_sampler_vs_reference_fixtures(dev, Cc):
+    """k_den_cluster (csrc/den_cluster.inc.hip) with fp32 weights against the fixtures generated from the reference modules:
+    one forward (scalar and per-sample timesteps, mld_denoiser.py:151-244) and the 50-step DDIM loop (mld.py:467-497)."""
+    g = load_golden("denoiser_N1.npz")
+    den = _with_cluster(make_den(dev), Cc)
+    s, c = torch.from_numpy(g["sample"]).to(dev), torch.from_numpy(g["cond"]).to(dev)
+    for t in (981, 501, 1):
+        y = den(sample=s, timestep=torch.tensor(t), encoder_hidden_states=c)[0]
+        assert rel_err(y.cpu().numpy(), g[f"out_t{t}"]) < TOL_F32
+    y = den(sample=s, timestep=torch.from_numpy(g["tvec"]).to(dev), encoder_hidden_states=c)[0]
+    assert rel_err(y.cpu().numpy(), g["out_tvec"]) < TOL_F32
+    gl = load_golden("ddim50_N1_B3.npz")
+    sch = _sched()
+    sch.set_timesteps(int(gl["steps"]))
+    out = den.sample_loop(torch.from_numpy(gl["latents"]).to(dev), torch.from_numpy(gl["cond_bf"]).to(dev), sch)
+    assert rel_err(out.cpu().numpy(), gl["out"]) < 5e-4
+    assert den.cluster_status()[0] == 0                       # no cluster gave up waiting for a peer
+
+
+@pytest.mark.parametrize("wd,tol", [("fp32", 1e-5), ("fp16", 5e-4), ("bf16", 5e-3)])
+def test_cluster_sampler_equals_one_cu_kernel(dev, wd, tol):
+    """Every cluster size, placement (one XCD / C XCDs) and granule-store flavour (L2-local / write-through) computes the same
+    latents as the one-CU-per-sample kernel on the same weight image dtype (contraction order differs: fp32 rounding), twice
+    bit-identically (the replicated epilogues of a cluster must agree bit for bit, and the sum over the publishers has a fixed
+    order); ragged batches (clusters beyond B exit), DDPM with injected step noise, per-sample timesteps."""
+    den = make_den(dev, weight_dtype=wd)
+    sch = _sched()
+    sch.set_timesteps(50)
+    torch.manual_seed(5)
+    lat, cond = torch.randn(32, 1, 256, device=dev), torch.randn(32, 1, 256, device=dev)
+    base = _with_cluster(den, 0).sample_loop(lat, cond, sch)
+    for Cc in (8, 4, 2):
+        for place in (0, 1):
+            for flags in (0, 1):
+                _with_cluster(den, Cc, place, flags)
+                z, z2 = den.sample_loop(lat, cond, sch), den.sample_loop(lat, cond, sch)
+                code, local = den.cluster_status()
+                assert code == 0
+                assert torch.equal(z, z2), (Cc, place, flags)
+                assert rel_err(z.cpu().numpy(), base.cpu().numpy()) < tol, (Cc, place, flags)
+                if flags == 1 or place == 1:
+                    assert local == 0                        # write-through requested, or the cluster spans XCDs
+    # ragged batch
+    z5 = _with_cluster(den, 8).sample_loop(lat[:5].contiguous(), cond[:5].contiguous(), sch)
+    assert rel_err(z5.cpu().numpy(), base[:, :5].cpu().numpy()) < tol
+    # DDPM ancestral steps with injected noise
+    schp = _sched("ddpm")
+    schp.set_timesteps(1000)
+    schp.timesteps = schp.timesteps[:40]
+    noise = torch.randn(40, 32, 256, device=dev)
+    bp = _with_cluster(den, 0).sample_loop(lat, cond, schp, step_noise=noise)
+    zp = _with_cluster(den, 8).sample_loop(lat, cond, schp, step_noise=noise)
+    assert rel_err(zp.cpu().numpy(), bp.cpu().numpy()) < tol
+    # one forward with per-sample timesteps
+    t = torch.randint(0, 1000, (32,), device=dev)
+    y0 = _with_cluster(den, 0)(sample=lat, timestep=t, encoder_hidden_states=cond.permute(1, 0, 2))[0]
+    y8 = _with_cluster(den, 8)(sample=lat, timestep=t, encoder_hidden_states=cond.permute(1, 0, 2))[0]
+    assert rel_err(y8.cpu().numpy(), y0.cpu().numpy()) < tol
+
+
+def test_cluster_sampler_under_uneven_load(dev):
+    """The in-launch exchanges (data-tagged granules, cdna_hip_programming.md Guideline 16 R2) under UNEVEN load: a second stream
+    keeps part of the chip busy with HBM-bound copies and small GEMMs while clusters sample; results must be bit-identical to
+    the quiet run for both store flavours, and no cluster may give up."""
+    den = make_den(dev, weight_dtype="fp16")
+    sch = _sched()
+    sch.set_timesteps(50)
+    torch.manual_seed(11)
+    lat, cond = torch.randn(24, 1, 256, device=dev), torch.randn(24, 1, 256, device=dev)
+    side = torch.cuda.Stream()
+    big = torch.randn(64 * 1024 * 1024, device=dev)
+    a = torch.randn(1024, 1024, device=dev)
+    for flags in (0, 1):
+        _with_cluster(den, 8, 0, flags)
+        quiet = den.sample_loop(lat, cond, sch)
+        torch.cuda.synchronize()
+        for rep in range(3):
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    big.mul_(1.0001)
+                    a = (a @ a).clamp_(-1, 1)
+            z = den.sample_loop(lat, cond, sch)
+            torch.cuda.synchronize()
+            assert den.cluster_status()[0] == 0
+            assert torch.equal(z, quiet), (flags, rep)
+
+
+def test_auto_cluster_policy(dev):
+    """cluster='auto': 8 / 4 / 2 CUs per sample while B x C fits one workgroup per CU, the one-CU kernel beyond, for CFG pairs,
+    several condition tokens and several heads."""
+    den = make_den(dev)
+    assert [den._cluster_size(B, 1, False) for B in (1, 32, 33, 64, 65, 128, 129, 256)] == [8, 8, 4, 4, 2, 2, 0, 0]
+    assert den._cluster_size(32, 2, False) == 0 and den._cluster_size(32, 1, True) == 0

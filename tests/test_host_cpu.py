@@ -378,3 +378,25 @@ def test_grouped_gemm_descriptor_layout_and_tiling():
         pr.tile0, pr.tiles_n = t0, tn
         t0 += n * max(1, pr.nbatch)
     assert (p.tile0, p.tiles_n, q.tile0, q.tiles_n, t0) == (0, 12, 48, 4, 48 + 16 * 7)
+
+
+def test_cluster_weight_image_indexing():
+    """seeme_amd.mld_denoiser.cluster_pack_stage against the indexing k_den_cluster applies (csrc/den_cluster.inc.hip: cl_issue /
+    cl_consume): wave w, unit u, load i of the unit -> stage load j = u UL + i -> k-block j // TPW, tile w TPW + j % TPW; lane
+    16 g + r, element e -> W[16 tile + r][KL kb + (KL / 4) g + e].  Both element widths, every tiles-per-wave count in use."""
+    import torch
+    from seeme_amd.mld_denoiser import cluster_pack_stage
+    g = torch.Generator().manual_seed(3)
+    for KL, UL in ((32, 8), (16, 16)):
+        for TPW, K in ((1, 256), (1, 512), (2, 128), (2, 256), (4, 256), (2, 512)):
+            W = torch.randn(8 * TPW * 16, K, generator=g)
+            img = cluster_pack_stage(W, TPW, KL, UL)
+            units = (K // KL) * TPW // UL
+            assert tuple(img.shape) == (units, 8, UL, 64, KL // 4)
+            for (u, w, i, lane, e) in [(0, 0, 0, 0, 0), (units - 1, 7, UL - 1, 63, KL // 4 - 1), (units // 2, 3, 5, 37, 2), (0, 6, 1, 16, 1)]:
+                j = u * UL + i
+                kb, t = j // TPW, j % TPW
+                row, col = 16 * (w * TPW + t) + (lane & 15), KL * kb + (KL // 4) * (lane >> 4) + e
+                assert img[u, w, i, lane, e] == W[row, col]
+            # every element appears exactly once
+            assert torch.equal(torch.sort(img.reshape(-1))[0], torch.sort(W.reshape(-1))[0])
