@@ -89,13 +89,28 @@ def den_executed_bytes(den, B, N, steps):
     return steps * per_step + B * per_sample
 
 
-def measured_traffic(weights, B, steps):
-    """HBM-side bytes per launch of the sampling kernel from the committed rocprofv3 PMC passes
-    (scripts/gpu_traffic.sh; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), if this exact config was profiled."""
+def den_cluster_bytes_per_cu(den, Cc, steps):
+    """Bytes ONE CU of a cluster streams per launch of k_den_cluster (csrc/den_cluster.inc.hip): its slice of in_proj' (+ the folded
+    skip linear in layers 3, 4), linear1, linear2 and the whole of ffn.linear1 / linear2 / proj_out (replicated), plus the per-layer
+    vectors and table rows, once per step."""
+    esize = 4 if den.weight_dtype == "fp32" else 2
+    D, FS, FF = 256, 1024, den.ff_size
+    S = D // Cc
+    a_plain, a_skip = 3 * S * D, 4 * S * 2 * D                         # q | k | v' rows; + y rows, K = 512
+    split = 2 * FS * D // Cc                                           # linear1 rows + linear2 columns of this CU
+    repl = 2 * FF * D + D * D
+    mats = 3 * (a_plain + split + repl) + 2 * (a_skip + split + repl)
+    return steps * (mats * esize + 5 * (6272 + 1536 + 1024 + 256) * 4)
+
+
+def measured_traffic(weights, B, steps, Cc=0):
+    """HBM-side bytes per launch of the sampling kernel from the committed rocprofv3 PMC passes (scripts/gpu_traffic.sh;
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), if this exact configuration was profiled: a constant read from
+    profiles/traffic.json, NOT observed in this run (PMC counters need the profiler around the process)."""
     path = os.path.join(REPO, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(f"{weights}_B{B}_steps{steps}")
+            return json.load(f).get(f"{weights}_B{B}_steps{steps}" + (f"_C{Cc}" if Cc else ""))
     except OSError:
         return None
 
@@ -211,13 +226,16 @@ def spawn_ranks(n, argv):
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     rc = 0
+    GRACE_S = 10.0          # a failed rank's siblings get this long to finish on their own (their own error message, their own
+    failed_at = None        # exit code) before they are terminated: in a collective they would otherwise wait for ever
     try:
         while any(p.poll() is None for p in procs):
-            for p in procs:
-                if p.poll() not in (None, 0):              # one rank died: the others would wait in a collective for ever
-                    for q in procs:
-                        if q.poll() is None:
-                            q.terminate()
+            if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+                failed_at = time.perf_counter()
+            if failed_at is not None and time.perf_counter() - failed_at > GRACE_S:
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
             time.sleep(0.2)
     finally:
         for p in procs:
@@ -370,6 +388,8 @@ def main():
                     help="--mode train: scene = scene + interactee (configs[2], default at 1 GPU), gimo = config_mld_gimo scene-only "
                          "(configs[3], default at N > 1), egobody = interactee only")
     ap.add_argument("--points", type=int, default=20000, help="--mode train: points per scene cloud")
+    ap.add_argument("--cluster", default=None, choices=["auto", "0", "2", "4", "8"],
+                    help="CUs per sample in the sampling kernel (default: the model's policy, 8 / 4 / 2 while B x C <= 256; 0 = one CU per sample)")
     ap.add_argument("--scheduler", default="ddim", choices=["ddim", "ddpm"], help="ddpm = 1000-step ancestral sampling (BASELINE configs[4])")
     args = ap.parse_args()
     if args.mode == "train" and args.batch == 32 and "--batch" not in sys.argv:
@@ -407,9 +427,14 @@ def main():
 
     B = args.batch
     S = max(1, args.streams)
-    if S > 1:       # batches in flight side by side: let the sampling kernel's workgroups be dealt to all XCDs (launch_den, den_kernels.hip)
-        os.environ.setdefault("SEEME_DEN_XCDS", "8")
+    # (S > 1, batches in flight side by side: the sampling kernel's workgroups are dealt to all XCDs -- pack_xcds = 8 below)
     models = [build_models(dev, args.weights, args.vae) for _ in range(S)]
+    if S > 1:       # ... and one CU per sample: a cluster launch wants the whole chip for ONE batch
+        for _, d, _ in models:
+            d.cluster, d.pack_xcds = 0, 8
+    if args.cluster is not None:
+        for _, d, _ in models:
+            d.cluster = args.cluster if args.cluster == "auto" else int(args.cluster)
     vae, den, sch = models[0]
     streams = [torch.cuda.Stream() for _ in range(S)]     # (side streams only: the legacy default stream serialises with all others)
     n_infer = DDIM_STEPS
@@ -482,9 +507,17 @@ def main():
         loop_ms = e0.elapsed_time(e1)
     alg_bytes = den_algorithmic_bytes(den, B, 1, n_infer)
     achieved = alg_bytes / (loop_ms * 1e-3) / 1e9
-    exe_bytes = den_executed_bytes(den, B, 1, n_infer)
-    cus = min(B, 256)                                   # one workgroup (one CU) per sample chain
-    per_cu = exe_bytes / (loop_ms * 1e-3) / 1e9         # every chain streams the image itself (from L2 / Infinity Cache)
+    Cc = den._cluster_size(B, 1, False)
+    if Cc:          # one sample split over Cc CUs: a CU streams its slices + the replicated FFN matrices
+        exe_cu = den_cluster_bytes_per_cu(den, Cc, n_infer)
+        cus = (B + 7) // 8 * 8 * Cc
+        exe_bytes = exe_cu * cus
+        kname = f"k_den_cluster (persistent DDIM loop, one sample split over {Cc} CUs)"
+    else:
+        exe_bytes = exe_cu = den_executed_bytes(den, B, 1, n_infer)
+        cus = min(B, 256)                               # one workgroup (one CU) per sample chain
+        kname = "k_den_sample (persistent DDIM loop, one CU per sample)"
+    per_cu = exe_cu / (loop_ms * 1e-3) / 1e9            # every CU streams its bytes itself (from L2 / Infinity Cache)
 
     if rank == 0:
         res = {
@@ -508,12 +541,13 @@ def main():
                        "batch_per_gpu": B, "seq_len": T_FRAMES, "ddim_steps": n_infer,
                        "parallelism": f"dp{world} (independent shards, no collective on the data path)"
                                       + (f", {S} batches in flight per GPU" if S > 1 else "") + (", hipGraph replay" if args.graph else "")},
-            "roofline": {"bound": "hbm", "kernel": "k_den_sample (persistent DDIM loop)",
+            "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.weights, B, n_infer),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.weights, B, n_infer, Cc),
+                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of this configuration; a committed constant, not observed in this run)",
                          "ms_per_launch": round(loop_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                         # what actually bounds this kernel: each sample chain streams the (reduced) weight image through ONE
-                         # CU's L1 fill path every step; measured ceiling of that path 118 GB/s (scripts/stream_probe3.py)
+                         # what the CUs actually stream (from L2 / Infinity Cache, never HBM: the image is 9-20 MB) and how close
+                         # each CU's L1 fill path runs to its measured ceiling of 118 GB/s (scripts/stream_probe3.py)
                          "executed_bytes_per_launch": int(exe_bytes),
                          "per_cu_stream": {"achieved": round(per_cu, 2), "peak": 118.0, "unit": "GB/s per CU",
                                            "frac": round(per_cu / 118.0, 4), "cus_busy": cus}},

@@ -204,6 +204,11 @@ typedef struct {
     const unsigned char* drop;   /* training forward only (with save): dropout keep-masks [B, SEEME_DEN_DROP_BYTES] of the MD layers'
                                   * nn.Dropout sites in training mode (layout csrc/den_train.h DM_*), or NULL (eval arithmetic) */
     float drop_scale;      /* 1 / (1 - p) */
+    int xcds;              /* seeme_denoiser_sample only: 0 or 8 = workgroups dealt to all XCDs; k in 1..7 = the working workgroups sit on
+                            * k XCDs (blockIdx % 8 < k; assumes the round-robin dispatch of SPX mode -- any other placement only changes which
+                            * L2s are shared, never results).  Fewer L2s re-fetching the 9 MB image each step: B = 32 on 2 XCDs pulls 962 MB per
+                            * 50-step launch from the Infinity Cache instead of 3.72 GB.  A choice of the CALLER (it knows whether the launch has
+                            * the chip to itself); the library keeps no state about streams. */
 } SeemeSampleArgs;
 #define SEEME_DEN_DROP_BYTES 10960
 
@@ -249,10 +254,11 @@ int seeme_den_train_pack(const float* const* mats, float* img_f, float* img_b, c
 int seeme_denoiser_backward(const SeemeDenoiserWeights* w, const void* img_bwd, int B, int N, const float* save,
                             const float* ctab, const float* ttab, const int32_t* trow, const float* dout,
                             float* gout, float* dctab, float* dttab, void* stream);
-/* The same with the dropout keep-masks the forward was given (SeemeSampleArgs.drop / drop_scale). */
+/* The same with the dropout keep-masks the forward was given (SeemeSampleArgs.drop / drop_scale) and the caller's XCD packing
+ * (SeemeSampleArgs.xcds; seeme_denoiser_backward runs unpacked). */
 int seeme_denoiser_backward_drop(const SeemeDenoiserWeights* w, const void* img_bwd, int B, int N, const float* save,
                                  const float* ctab, const float* ttab, const int32_t* trow, const float* dout,
-                                 float* gout, float* dctab, float* dttab, const unsigned char* drop, float drop_scale, void* stream);
+                                 float* gout, float* dctab, float* dttab, const unsigned char* drop, float drop_scale, int xcds, void* stream);
 
 /* Offsets of the packed weight image (30 per layer x 5, then pe0, fnw, fnb, wg_total, vp_total). */
 int seeme_den_layout(int ff_sa, int ff, int64_t* out, int cap);

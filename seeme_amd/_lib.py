@@ -84,7 +84,7 @@ class DenoiserWeights(C.Structure):
 class SampleArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("N", C.c_int), ("steps", C.c_int), ("sched", C.c_int), ("cfg", C.c_int),
                 ("guidance_scale", C.c_float), ("latents", fp), ("ctab", fp), ("ttab", fp), ("trow", fp),
-                ("trow_per_sample", C.c_int), ("coef", fp), ("noise", fp), ("out", fp), ("catab", fp), ("save", fp), ("force_query", C.c_int), ("drop", fp), ("drop_scale", C.c_float)]
+                ("trow_per_sample", C.c_int), ("coef", fp), ("noise", fp), ("out", fp), ("catab", fp), ("save", fp), ("force_query", C.c_int), ("drop", fp), ("drop_scale", C.c_float), ("xcds", C.c_int)]
 
 
 class DenCluster(C.Structure):
@@ -176,7 +176,7 @@ _SIGNATURES = {
     "seeme_den_train_layout": (C.c_int, [C.POINTER(C.c_int64), C.c_int]),
     "seeme_den_train_pack": (C.c_int, [fp, fp, fp, fp, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.c_int, fp, fp]),
     "seeme_denoiser_backward": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp]),
-    "seeme_denoiser_backward_drop": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_float, fp]),
+    "seeme_denoiser_backward_drop": (C.c_int, [C.POINTER(DenoiserWeights), fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_float, C.c_int, fp]),
     "seeme_den_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "seeme_den_wgrad": (C.c_int, [fp, C.c_int, C.c_int, fp, C.c_int, fp, fp]),
     "seeme_adamw_step": (C.c_int, [fp, C.c_int, fp, fp, fp, fp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
@@ -224,6 +224,18 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib().seeme_last_error().decode("utf-8", "replace")
         raise SeemeError(f"{what or 'seeme_hip'} failed (rc={rc}): {msg}")
+
+
+def default_xcds(chains: int, want="auto") -> int:
+    """How many XCDs the working workgroups of a one-CU-per-chain launch sit on (SeemeSampleArgs.xcds): `want` = "auto" packs ~16
+    chains per XCD -- right for a launch that has the chip to itself (one stream); callers that keep several launches in flight
+    pass 8 (dealt over all XCDs).  SEEME_DEN_XCDS overrides (timing experiments, tests/test_gpu_flows.py)."""
+    e = os.environ.get("SEEME_DEN_XCDS")
+    if e is not None:
+        want = int(e)
+    if want == "auto":
+        want = (chains + 15) // 16
+    return min(8, max(1, int(want)))
 
 
 def ptr(t) -> int:

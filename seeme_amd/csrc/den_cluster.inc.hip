@@ -189,7 +189,7 @@ __device__ __forceinline__ void cl_store_granule(unsigned long long* g, unsigned
     if (local) *(volatile dcl_gu64*)g = x;                                                       // stays in this XCD's L2
     else __hip_atomic_store((dcl_gu64*)g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // sc1: write-through
 }
-__device__ __forceinline__ bool cl_tags_ok(const u32x4& a, unsigned epoch) { return (a.y == epoch) & (a.w == epoch); }
+__device__ __forceinline__ unsigned cl_tags_ok(const u32x4& a, unsigned epoch) { return (unsigned)(a.y == epoch) & (unsigned)(a.w == epoch); }   // (no short-circuit branches)
 
 template <typename WT, int C>
 __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
@@ -366,9 +366,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                     }
                     gs0 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_s, 0, 16);
                     gs1 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_s + 16, 0, 16);
-                    const bool ok = cl_tags_ok(gv0, epoch) & cl_tags_ok(gv1, epoch) & cl_tags_ok(gy0, epoch) & cl_tags_ok(gy1, epoch)
+                    const unsigned ok = cl_tags_ok(gv0, epoch) & cl_tags_ok(gv1, epoch) & cl_tags_ok(gy0, epoch) & cl_tags_ok(gy1, epoch)
                                   & cl_tags_ok(gs0, epoch) & cl_tags_ok(gs1, epoch);
-                    if (__all(ok) || dead) break;
+                    if (__all(ok != 0u) || dead) break;
                     if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 2u); break; }
                 }
                 DEN_DBG(0);
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                         g[p][0] = __builtin_amdgcn_raw_buffer_load_b128(xr_, o, 0, 16);
                         g[p][1] = __builtin_amdgcn_raw_buffer_load_b128(xr_, o + 16, 0, 16);
                     }
-                    bool ok = true;
+                    unsigned ok = 1u;
                     sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int p = 0; p < C; ++p) {
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                         sum.x += __uint_as_float(g[p][0].x); sum.y += __uint_as_float(g[p][0].z);
                         sum.z += __uint_as_float(g[p][1].x); sum.w += __uint_as_float(g[p][1].z);
                     }
-                    if (__all(ok) || dead) break;
+                    if (__all(ok != 0u) || dead) break;
                     if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 4u); break; }
                 }
                 DEN_DBG(0);

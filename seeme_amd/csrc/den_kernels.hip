@@ -982,17 +982,17 @@ static size_t den_lds_bytes(int MS, int N, bool mfma) {
     return (size_t)(768 + MS * 768 + 2 * (VP_LAYER + STG_TT + MS * N * 1024 + (N > 1 ? 0 : MS * 256)) + XB_FLOATS(mfma, MS) + (mfma ? MS * 1024 : 4 * MS * 768)) * sizeof(float);
 }
 
-// XCD packing is for a launch that has the chip to itself.  Launches on several streams at once (batches in flight side by side)
-// would all pack onto the SAME XCDs -- measured: two streams 12.7 k seqs/s packed vs 13.3 k dealt round-robin, eight graph-replayed
-// streams 13.1 k vs 16.1 k; rotating the XCD set per launch instead costs the single stream its L2 contents (4.58 -> 4.63 ms).
-// So: the first stream this process ever samples on packs, every other stream is dealt round-robin (SEEME_DEN_XCDS overrides).
-static bool den_pack_on_stream(hipStream_t st) {
-    static std::atomic<int> state{0};
-    static hipStream_t first;
-    int expected = 0;
-    if (state.compare_exchange_strong(expected, 1)) { first = st; state.store(2); }
-    while (state.load() != 2) {}
-    return st == first;
+// XCD packing (SeemeSampleArgs.xcds): workgroups go to the 8 XCDs round-robin (SPX mode), and every XCD's L2 (4 MB) pulls the whole weight
+// image (9 MB at 16 bit) from the Infinity Cache once per step whether 4 or 16 of its CUs consume it.  ~16 chains per XCD measured best
+// (B=32: 2 XCDs 4.64 ms, 4: 4.67, 8: 4.74, 1: 4.86 -- 32 CUs on one L2 run into its bandwidth).  It pays for a launch that has the chip
+// to itself: two streams packed onto the same two XCDs 12.7 k seqs/s vs 13.3 k dealt out, eight graph-replayed streams 13.1 k vs 16.1 k --
+// which only the caller knows, so the count is an argument (seeme_amd/_lib.py default_xcds) and the library keeps no stream state.
+// One mapping for the sampling and the backward kernel: grid = 8 * ceil(chains / k) workgroups, blockIdx % 8 >= k return at once.
+static int den_xcd_grid(int chains, int want, int* xcds) {
+    int k = (want >= 1 && want <= 7) ? want : 8;
+    if (chains > 32 * k) k = 8;                                  // one workgroup per CU, 32 CUs per XCD
+    *xcds = k;
+    return k < 8 ? (chains + k - 1) / k * 8 : chains;
 }
 template <typename WT, int MS, int V>
 static int launch_den(const DenKArgs& ka, hipStream_t st) {
@@ -1000,17 +1000,9 @@ static int launch_den(const DenKArgs& ka, hipStream_t st) {
     const size_t lds = den_lds_bytes(MS, ka.s.N, WT::MFMA);
     if (lds > 160 * 1024) return seeme_fail("denoiser_sample: LDS budget exceeded");
     SEEME_HIP(hipFuncSetAttribute((const void*)k_den_sample<WT, MS, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // Workgroups go to the 8 XCDs round-robin, and every XCD's L2 (4 MB) pulls the whole weight image (9 MB at 16 bit) from the
-    // Infinity Cache once per step whether 4 or 16 of its CUs consume it.  ~16 chains per XCD measured best (B=32: 2 XCDs 4.64 ms,
-    // 4: 4.67, 8: 4.74, 1: 4.86 -- 32 CUs on one L2 run into its bandwidth); SEEME_DEN_XCDS=1..8 forces a count.
-    static int want = -1;
-    if (want < 0) { const char* e = getenv("SEEME_DEN_XCDS"); want = e ? atoi(e) : 0; if (want < 0 || want > 8) want = 0; }
     DenKArgs k2 = ka;
     k2.chains = chains;
-    k2.xcds = want ? want : (chains + 15) / 16;
-    if (k2.xcds > 8 || chains > 32 * k2.xcds) k2.xcds = 8;      // one workgroup per CU, 32 CUs per XCD
-    if (!want && !den_pack_on_stream(st)) k2.xcds = 8;
-    const int grid = k2.xcds < 8 ? (chains + k2.xcds - 1) / k2.xcds * 8 : chains;
+    const int grid = den_xcd_grid(chains, ka.s.xcds, &k2.xcds);
     hipLaunchKernelGGL((k_den_sample<WT, MS, V>), dim3(grid), dim3(DEN_THREADS), lds, st, k2);
     return seeme_check_launch("k_den_sample");
 }

@@ -423,13 +423,13 @@ static_assert(DM_TOTAL == SEEME_DEN_DROP_BYTES, "dropout mask block: header cons
 extern "C" int seeme_denoiser_backward(const SeemeDenoiserWeights* w, const void* img_bwd, int B, int N, const float* save,
                                        const float* ctab, const float* ttab, const int32_t* trow, const float* dout,
                                        float* gout, float* dctab, float* dttab, void* stream) {
-    return seeme_denoiser_backward_drop(w, img_bwd, B, N, save, ctab, ttab, trow, dout, gout, dctab, dttab, nullptr, 1.f, stream);
+    return seeme_denoiser_backward_drop(w, img_bwd, B, N, save, ctab, ttab, trow, dout, gout, dctab, dttab, nullptr, 1.f, 0, stream);
 }
 
 extern "C" int seeme_denoiser_backward_drop(const SeemeDenoiserWeights* w, const void* img_bwd, int B, int N, const float* save,
                                             const float* ctab, const float* ttab, const int32_t* trow, const float* dout,
                                             float* gout, float* dctab, float* dttab, const unsigned char* drop, float drop_scale,
-                                            void* stream) {
+                                            int xcds, void* stream) {
     if (B <= 0) return seeme_fail("denoiser_backward: B must be > 0");
     if (N < 1 || N > DEN_MAXTOK - 2) return seeme_fail("denoiser_backward: 1 <= N <= 4 condition tokens");
     if (w->nhead != 1 || w->sa_fold || w->wdtype != 0) return seeme_fail("denoiser_backward: one head, unfolded fp32 image");
@@ -440,12 +440,7 @@ extern "C" int seeme_denoiser_backward_drop(const SeemeDenoiserWeights* w, const
     a.B = B; a.N = N; a.save = save; a.ctab = ctab; a.ttab = ttab; a.trow = trow; a.dout = dout;
     a.drop = drop; a.drop_scale = drop_scale;
     a.gout = gout; a.dctab = dctab; a.dttab = dttab;
-    static int want = -1;
-    if (want < 0) { const char* e = getenv("SEEME_DEN_XCDS"); want = e ? atoi(e) : 0; if (want < 0 || want > 8) want = 0; }
-    a.xcds = want ? want : (B + 15) / 16;
-    if (a.xcds > 8 || B > 32 * a.xcds) a.xcds = 8;
-    if (!want && !den_pack_on_stream((hipStream_t)stream)) a.xcds = 8;
-    const int grid = a.xcds < 8 ? (B + a.xcds - 1) / a.xcds * 8 : B;
+    const int grid = den_xcd_grid(B, xcds, &a.xcds);
     hipLaunchKernelGGL(k_den_bwd, dim3(grid), dim3(DEN_THREADS), 0, (hipStream_t)stream, a);
     return seeme_check_launch("k_den_bwd");
 }

@@ -307,6 +307,7 @@ class _Chain(torch.autograd.Function):
         a.save, a.force_query = save.data_ptr(), 1
         masks, scale = draw_dropout_masks(pack.den, B)
         a.drop, a.drop_scale = L.ptr(masks), scale
+        a.xcds = L.default_xcds(B)
         L.check(L.lib().seeme_denoiser_sample(C.byref(pack.w), C.byref(a), L.current_stream()), "seeme_denoiser_sample")
         ctx.pack, ctx.N, ctx.masks, ctx.drop_scale = pack, N, masks, scale
         pack.last_masks = masks
@@ -324,7 +325,7 @@ class _Chain(torch.autograd.Function):
         L.check(L.lib().seeme_denoiser_backward_drop(C.byref(pack.w), pack.img_b.data_ptr(), B, N, save.data_ptr(), ctab.data_ptr(),
                                                       ttab.data_ptr(), trow.data_ptr(), dout.contiguous().data_ptr(), gout.data_ptr(),
                                                       dctab.data_ptr(), dttab.data_ptr(), L.ptr(ctx.masks), ctx.drop_scale,
-                                                      L.current_stream()), "seeme_denoiser_backward")
+                                                      L.default_xcds(B), L.current_stream()), "seeme_denoiser_backward")
         # the chain's own parameters do not travel through autograd: their gradients are reduced straight into .grad
         pack.reduce_into_grads(gout)
         fin = 5 * lay["DB_LAYER"]

@@ -165,6 +165,7 @@ class MldDenoiser(nn.Module):
         self.cluster = cluster
         self.cluster_placement = 0       # 0: a cluster's workgroups share an XCD (round-robin dispatch), 1: spread over C XCDs
         self.cluster_flags = 0           # bit 0: write-through granule stores always
+        self.pack_xcds = "auto"          # one-CU-per-sample launches: XCDs the working workgroups sit on (_lib.default_xcds); 8 = dealt out
 
         d = self.latent_dim
         self.time_embedding = _TimestepEmbeddingParams(text_encoded_dim, d)
@@ -423,6 +424,7 @@ class MldDenoiser(nn.Module):
         a.coef, a.noise, a.out = L.ptr(coef), L.ptr(noise), out.data_ptr()
         catab = self.ca_tables(ctab, ttab, trow, per_sample) if N == 1 else None
         a.catab = L.ptr(catab)
+        a.xcds = L.default_xcds((B + 1) // 2 if (B > 256 and not per_sample and not cfg) else B, self.pack_xcds)
         w = self._weights()
         Cc = self._cluster_size(B, N, bool(cfg))
         if Cc:

@@ -305,6 +305,7 @@ class Stage2Glue:
         s.save, s.force_query = plan.save.data_ptr(), 1
         plan.masks, plan.drop_scale = draw_dropout_masks(self.den, B, out=plan.drop)
         s.drop, s.drop_scale = L.ptr(plan.masks), plan.drop_scale
+        s.xcds = L.default_xcds(B)
         L.check(L.lib().seeme_denoiser_sample(C.byref(pack.w), C.byref(s), st), "seeme_denoiser_sample")
         plan.busy = True
         plan._keep = (dist, eps_z, eps_c, noise, timesteps)
@@ -317,7 +318,7 @@ class Stage2Glue:
         L.check(L.lib().seeme_denoiser_backward_drop(C.byref(pack.w), pack.img_b.data_ptr(), B, N, plan.save.data_ptr(), plan.ctab.data_ptr(),
                                                       plan.ttab.data_ptr(), plan.trow.data_ptr(), dout.contiguous().data_ptr(),
                                                       plan.gout.data_ptr(), plan.dctab.data_ptr(), plan.dttab.data_ptr(),
-                                                      L.ptr(plan.masks), plan.drop_scale, st), "seeme_denoiser_backward")
+                                                      L.ptr(plan.masks), plan.drop_scale, L.default_xcds(B), st), "seeme_denoiser_backward")
         pack.reduce_into_grads(plan.gout)            # chain weights (overwrites its block of the bucket) -- BEFORE the accumulations below
         plan.bind_grads(self)
         plan.g_b0.launch()
