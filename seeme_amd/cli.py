@@ -134,7 +134,9 @@ def build(cfg, dev, args, datamodule=None, smpl_model=None):
         from .data import EgoDataModule
         datamodule = EgoDataModule(args.data_root, cfg.DATASET_NAME, tuple(cfg.model.condition), motion_length=int(cfg.MOTION_LENGTH),
                                    predict_transl=bool(cfg.TRAIN.ABLATION.PREDICT_TRANSL), device=dev, storage=args.storage,
-                                   scene_root=args.scene_root, pose_estimation_task=bool(cfg.TEST.get("POSE_ESTIMATION_TASK", False)))
+                                   scene_root=args.scene_root, pose_estimation_task=bool(cfg.TEST.get("POSE_ESTIMATION_TASK", False)),
+                                   interactee_pred=bool(cfg.TEST.get("INTERACTEE_PRED", False)),      # get_data.py:196
+                                   seed=int(cfg.SEED_VALUE))
     dm = datamodule or SyntheticEgoDataModule(nfeats=nfeats, T=args.frames, n_points=args.scene_points,
                                                seed=int(cfg.SEED_VALUE), device=dev)
     if smpl_model is None and not os.path.exists(str(cfg.model.smpl_path)):
@@ -191,17 +193,24 @@ def train_main(argv: Optional[List[str]] = None, datamodule=None, smpl_model=Non
     for epoch in range(start_epoch, end_epoch):
         model.losses["train"].reset()
         t0 = time.perf_counter()
-        for it in range(args.iters_per_epoch):
-            batch = dm.batch(B, idx=(epoch * args.iters_per_epoch + it) * ws + rank, with_scene=_with_scene(cfg))
+        if hasattr(dm, "iterate"):      # files: one pass over the train split per epoch, a new permutation each, ranks take disjoint
+            # strided shares (what the reference's DataLoader + DistributedSampler do, train.py:127-149); drop_last keeps the ranks in step
+            batches = dm.iterate("train", B, shuffle=True, seed=int(cfg.SEED_VALUE), epoch=epoch, rank=rank, world=ws, drop_last=True)
+        else:                           # synthetic stream: `iters_per_epoch` fresh batches
+            batches = (dm.batch(B, idx=(epoch * args.iters_per_epoch + it) * ws + rank, with_scene=_with_scene(cfg))
+                       for it in range(args.iters_per_epoch))
+        n_it = 0
+        for it, batch in enumerate(batches):
             loss = model.training_step(batch, it)
             model.optimizer_step(loss)
             global_step += 1
+            n_it += 1
         if getattr(model, "sch", None) is not None:
             model.sch.step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         sums = model.losses["train"].compute()
-        last = {"epoch": epoch, "step": global_step, "seqs_per_s": round(ws * B * args.iters_per_epoch / dt, 1),
+        last = {"epoch": epoch, "step": global_step, "seqs_per_s": round(ws * B * n_it / dt, 1),
                 **{k: round(v, 6) for k, v in sums.items()}}
         log.info("epoch %d: %s", epoch, json.dumps(last))
         if rank == 0 and ((epoch + 1) % save_every == 0 or epoch + 1 == end_epoch):
@@ -239,14 +248,20 @@ def test_main(argv: Optional[List[str]] = None, datamodule=None, smpl_model=None
         model.EgoMetric.reset()
         t0 = time.perf_counter()
         with torch.no_grad():
-            for it in range(args.test_batches):
-                batch = dm.batch(B, idx=10_000_000 + it * ws + rank, with_scene=_with_scene(cfg), split="test")
+            if hasattr(dm, "iterate"):  # files: ONE pass over the test split, every sequence exactly once over the ranks (test.py:115-133)
+                batches = dm.iterate("test", B, rank=rank, world=ws)
+            else:
+                batches = (dm.batch(B, idx=10_000_000 + it * ws + rank, with_scene=_with_scene(cfg), split="test")
+                           for it in range(args.test_batches))
+            n_seq = 0
+            for it, batch in enumerate(batches):
                 model.test_step(batch, it)
+                n_seq += int(batch[0].shape[0])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         sums = D.reduce_sums(model.EgoMetric.sums().to(dev)).cpu()
         metrics = model.EgoMetric.compute(sums)
-        metrics["seqs_per_s"] = ws * B * args.test_batches / dt
+        metrics["seqs_per_s"] = ws * n_seq / dt
         log.info("Replication %d: %s", rep, json.dumps({k: round(v, 4) for k, v in metrics.items()}))
         for k, v in metrics.items():
             all_metrics.setdefault(k, []).append(float(v))

@@ -21,9 +21,13 @@ On-disk layout (what the reference reads; the datasets themselves are licence-ga
     EgoBody scenes (``condition`` contains 'scene'), under <scene_root>:
         map_dict_<split>.pkl {image name -> scene key}, pcd_verts_dict_<split>.pkl {scene key -> [P,3] cloud, kinect frame},
         transf_matrices_all_seqs.pkl {sequence -> {trans_kinect2holo [4,4], trans_world2pv {timestamp -> [4,4]}}}
-    GIMO scenes: <scene_root>/<scene>/scene_obj/{transform_norm.txt, scene_points.npy}; the reference samples 20000 vertices
-        of ``scene_downsampled.ply`` through trimesh (absent here) -- a one-off conversion of the mesh vertices to
-        ``scene_points.npy`` replaces that dependency.
+    GIMO scenes: <scene_root>/<scene>/scene_obj/{transform_norm.txt, scene_points.npy}; the reference reads the vertices of
+        ``scene_downsampled.ply`` through trimesh (absent here) -- a one-off conversion of ALL mesh vertices to ``scene_points.npy``
+        replaces that dependency.  As in the reference (dataset.py:2013-2033) every item draws 20000 vertices with replacement
+        from its scene on every access, and the train split adds N(0, 0.01) jitter: done on the device from a seedable generator
+        (or from injected draws, for the tests).
+    Optional <root>/interactee_pred_<split>.pkl {image name -> {"smpl_parameters": {global_orient, body_pose, betas}}}: EgoHMR
+        estimates that replace the interactee's pose as the CONDITION (dataset.py:1215-1223, 1300-1321; translation stays the file's).
 
 Files are read with loaders that execute nothing: ``np.load(allow_pickle=False)`` for arrays, and for the pickled ``.npy`` /
 ``.pkl`` containers an unpickler that only admits numpy array reconstruction and plain containers.
@@ -80,7 +84,8 @@ class EgoSequenceSplit:
 
     def __init__(self, root: str, split: str, dataset: str = "egobody", condition: Sequence[str] = ("text", "interactee"),
                  motion_length: int = 60, data_type: str = "angle", predict_transl: bool = True,
-                 pose_estimation_task: bool = False, scene_root: Optional[str] = None, max_items: Optional[int] = None):
+                 pose_estimation_task: bool = False, scene_root: Optional[str] = None, max_items: Optional[int] = None,
+                 interactee_pred: Optional[str] = None, scene_points: int = 20000):
         if data_type != "angle":
             raise NotImplementedError("data module: DATA_TYPE 'angle' (the rot6d variant re-encodes the same files)")
         self.dataset, self.split, self.condition = dataset, split, tuple(condition)
@@ -104,6 +109,13 @@ class EgoSequenceSplit:
         utils = np.zeros((N, T, 6), np.float32)
         length = np.zeros((N, 1), np.int32)
         self.names, self.images = names, []
+        self.scene_points = int(scene_points)
+        pred = load_pickled(interactee_pred) if interactee_pred else None            # EgoHMR estimates (dataset.py:1215-1223)
+        pe = self.pose_estimation_task
+        # POSE_ESTIMATION_TASK: the file's own interactee is the ground truth the estimate is scored against (dataset.py:1255-1256,
+        # 1333-1342); without `interactee_pred` it coincides with the condition
+        pe_motion = np.zeros((N, T, 1, self.numdims), np.float32) if pe else None
+        pe_beta = np.zeros((N, T, 1, 10), np.float32) if pe else None
         first_image: List[str] = []
         m, s = self.mean[0], self.std[0]
         t_lo = self.numdims if dataset == "egobody" else m.shape[0] - 3                    # EgoBody: [numdims, +3); GIMO: the last three (:1607-1612, 2360-2364)
@@ -124,18 +136,30 @@ class EgoSequenceSplit:
                 go[:L] = np.asarray(sp["global_orient"], np.float32).reshape(L, 3)
                 bp[:L] = np.asarray(sp["body_pose"], np.float32).reshape(L, -1)[:, : self.pose_dim]
                 tr[:L] = np.asarray(sp["transl"], np.float32).reshape(L, 3)
+                bt = np.asarray(sp["betas"], np.float32).reshape(L, 10)
+                if p == 1 and pe:
+                    pe_motion[i, :, 0, : self.go_dims] = (go - m[: self.go_dims]) / s[: self.go_dims]
+                    pe_motion[i, :, 0, self.go_dims:] = (bp - m[self.go_dims: self.numdims]) / s[self.go_dims: self.numdims]
+                    pe_beta[i, :L, 0] = bt
+                if p == 1 and pred is not None:                                                # estimates, per image (:1300-1321)
+                    est = [pred[str(im)]["smpl_parameters"] for im in self.images[-1][:L]]
+                    go[:L] = np.stack([np.asarray(e["global_orient"], np.float32).reshape(3) for e in est])
+                    bp[:L] = np.stack([np.asarray(e["body_pose"], np.float32).reshape(-1)[: self.pose_dim] for e in est])
+                    bt = np.stack([np.asarray(e["betas"], np.float32).reshape(10) for e in est])
                 # zero padding comes BEFORE the normalisation, as in the reference (:1524-1546): padded frames are -mean/std
                 motion[i, :, p, : self.go_dims] = (go - m[: self.go_dims]) / s[: self.go_dims]
                 motion[i, :, p, self.go_dims:] = (bp - m[self.go_dims: self.numdims]) / s[self.go_dims: self.numdims]
                 if self.predict_transl:
                     tr = (tr - m[t_lo: t_lo + 3]) / s[t_lo: t_lo + 3]
                 transl[i, p] = tr
-                beta[i, p, :L] = np.asarray(sp["betas"], np.float32).reshape(L, 10)
+                beta[i, p, :L] = bt
             cols = [np.asarray(ru[k], np.float32).reshape(L, -1) for k in ("fx", "cx", "cy", "center", "scale")]
             utils[i, :L] = np.concatenate(cols, axis=1)                                        # [L, 1+1+1+2+1] (:1584-1586)
         self.motion, self.transl, self.beta = torch.from_numpy(motion), torch.from_numpy(transl), torch.from_numpy(beta)
         self.utils, self.length = torch.from_numpy(utils), torch.from_numpy(length)
-        self.scene_table = self.scene_index = self.scene_xform = None
+        self.pe_motion = torch.from_numpy(pe_motion) if pe else None
+        self.pe_beta = torch.from_numpy(pe_beta) if pe else None
+        self.scene_table = self.scene_index = self.scene_xform = self.scene_flat = self.scene_off = self.scene_cnt = None
         if "scene" in self.condition:
             self._load_scenes(scene_root or root, first_image)
 
@@ -159,7 +183,7 @@ class EgoSequenceSplit:
                     keys[key] = len(clouds)
                     clouds.append(np.asarray(verts[key], np.float32))
                 idx[i] = keys[key]
-        else:                                                                                  # GIMO: dataset.py:1989-2031 (eval form: no jitter)
+        else:                                                                                  # GIMO: dataset.py:1989-2033
             scale = 1.03
             for i, img in enumerate(first_image):
                 key = img.split("/")[-4]
@@ -170,34 +194,64 @@ class EgoSequenceSplit:
                 tn = np.loadtxt(os.path.join(scene_root, key, "scene_obj", "transform_norm.txt")).reshape(4, 4).astype(np.float32)
                 tn[:3, 3] /= scale
                 xform[i], idx[i] = tn, keys[key]
-        P = min(c.shape[0] for c in clouds)
-        self.scene_table = torch.from_numpy(np.stack([c[:P] for c in clouds]))              # [S,P,3]
         self.scene_index, self.scene_xform = torch.from_numpy(idx), torch.from_numpy(xform)
+        if self.dataset == "egobody":                # one fixed cloud per scene key, used as it is (dataset.py:1265-1286)
+            P = min(c.shape[0] for c in clouds)
+            self.scene_table = torch.from_numpy(np.stack([c[:P] for c in clouds]))          # [S,P,3]
+        else:                                        # GIMO: ALL vertices of every scene; items sample from them on every access
+            cnt = np.array([c.shape[0] for c in clouds], np.int64)
+            self.scene_flat = torch.from_numpy(np.concatenate(clouds, axis=0))              # [sum V,3]
+            self.scene_cnt = torch.from_numpy(cnt)
+            self.scene_off = torch.from_numpy(np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64))
 
     def __len__(self):
         return self.motion.shape[0]
 
     def to(self, device, pinned: bool = False):
-        for k in ("motion", "transl", "beta", "utils", "length", "scene_table", "scene_index", "scene_xform"):
+        for k in ("motion", "transl", "beta", "utils", "length", "scene_table", "scene_index", "scene_xform", "scene_flat", "scene_off",
+                  "scene_cnt", "pe_motion", "pe_beta"):
             t = getattr(self, k)
             if t is not None:
                 setattr(self, k, t.pin_memory() if pinned else t.to(device))
         return self
 
-    def scenes(self, index: torch.Tensor) -> torch.Tensor:
-        """points_coord_trans(cloud, M) = cloud @ M[:3,:3]^T + M[:3,3] (utils_egobody/geometry.py:324-328) for a batch of items."""
+    @property
+    def has_scene(self) -> bool:
+        return self.scene_table is not None or self.scene_flat is not None
+
+    def scenes(self, index: torch.Tensor, generator: Optional[torch.Generator] = None, draws=None) -> torch.Tensor:
+        """The scene clouds of a batch of items, in the frame the reference hands to the model.
+        EgoBody: points_coord_trans(cloud, M) = cloud @ M[:3,:3]^T + M[:3,3] (utils_egobody/geometry.py:324-328).
+        GIMO (dataset.py:2013-2033): per item `scene_points` vertices drawn with replacement from ALL vertices of its scene
+        (np.random.choice there; here floor(u V) from `generator` on the device), the norm transform, and in the train split
+        N(0, 0.01) jitter.  `draws` = (u [B,P] in [0,1), noise [B,P,3] standard normal or None) injects the random numbers."""
         M = self.scene_xform.index_select(0, index)
-        pts = self.scene_table.index_select(0, self.scene_index.index_select(0, index))
-        return torch.baddbmm(M[:, None, :3, 3], pts, M[:, :3, :3].transpose(1, 2))
+        if self.scene_table is not None:
+            pts = self.scene_table.index_select(0, self.scene_index.index_select(0, index))
+            return torch.baddbmm(M[:, None, :3, 3], pts, M[:, :3, :3].transpose(1, 2))
+        dev, B, P = self.scene_flat.device, index.shape[0], self.scene_points
+        sc = self.scene_index.index_select(0, index)
+        cnt, off = self.scene_cnt.index_select(0, sc), self.scene_off.index_select(0, sc)
+        u = draws[0].to(dev) if draws is not None else torch.rand(B, P, device=dev, generator=generator)
+        pick = torch.minimum((u.double() * cnt[:, None].double()).long(), cnt[:, None] - 1) + off[:, None]
+        pts = self.scene_flat.index_select(0, pick.reshape(-1)).reshape(B, P, 3)
+        pts = torch.baddbmm(M[:, None, :3, 3], pts, M[:, :3, :3].transpose(1, 2))
+        if self.split == "train":
+            noise = draws[1] if draws is not None else torch.randn(B, P, 3, device=dev, generator=generator)
+            if noise is not None:
+                pts = pts + 0.01 * noise.to(dev)
+        return pts
 
     def item(self, i: int):
         """The tuple ``__getitem__`` returns in the reference (:1754-1794, 2479-2509), for one sequence."""
         ix = torch.tensor([i], device=self.motion.device)
         out = [self.motion[i], self.transl[i], self.beta[i], self.utils[i]]
-        if self.scene_table is not None:
+        if self.has_scene:
             out.append(self.scenes(ix)[0])
         out.append(self.length[i])
-        if self.scene_table is not None and not self.pose_estimation_task:
+        if self.pose_estimation_task:            # (motion_interacte_pe_gt, interactee_transl_pe_gt, interactee_beta_pe_gt), :1765-1781
+            out += [self.pe_motion[i], self.transl[i, 1:2], self.pe_beta[i]]
+        elif self.has_scene:
             out.append(self.images[i])
         return tuple(out)
 
@@ -210,7 +264,7 @@ class EgoDataModule:
     def __init__(self, root: str, dataset: str = "egobody", condition: Sequence[str] = ("text", "interactee"),
                  motion_length: int = 60, predict_transl: bool = True, device="cuda", storage: str = "device",
                  scene_root: Optional[str] = None, pose_estimation_task: bool = False, splits: Sequence[str] = ("train", "val", "test"),
-                 max_items: Optional[int] = None):
+                 max_items: Optional[int] = None, interactee_pred: bool = False, scene_points: int = 20000, seed: int = 1234):
         if storage not in ("device", "pinned"):
             raise ValueError("storage: 'device' (split resident in HBM) or 'pinned' (pinned host memory, async copies)")
         self.name, self.device, self.storage = dataset, torch.device(device), storage
@@ -222,16 +276,18 @@ class EgoDataModule:
         for sp in splits:
             d = os.path.join(root, "test" if (dataset == "gimo" and sp == "val") else sp)
             if os.path.isdir(d):
+                pred = os.path.join(root, f"interactee_pred_{sp}.pkl") if interactee_pred else None
                 s = EgoSequenceSplit(root, sp, dataset, condition, motion_length, "angle", predict_transl, pose_estimation_task,
-                                     scene_root, max_items)
+                                     scene_root, max_items, pred, scene_points)
                 self.splits[sp] = s.to(self.device, pinned=(storage == "pinned"))
         if not self.splits:
             raise FileNotFoundError(f"no split directory under {root}")
         any_split = next(iter(self.splits.values()))
         self.mean = torch.from_numpy(any_split.mean).to(self.device)
         self.std = torch.from_numpy(any_split.std).to(self.device)
-        self.with_scene = any_split.scene_table is not None
+        self.with_scene = any_split.has_scene
         self.pose_estimation_task = pose_estimation_task
+        self.generator = torch.Generator(device=self.device if storage == "device" else "cpu").manual_seed(int(seed))   # scene sampling / jitter
 
     def renorm(self, features):
         """features * std[0, :numdims] + mean[0, :numdims]  (EgoBody.py:151-157, Gimo.py:139-145).  For GIMO the translation
@@ -248,12 +304,14 @@ class EgoDataModule:
         ix = index.to(s.motion.device)
         sel = lambda t: t.index_select(0, ix)
         out = [sel(s.motion), sel(s.transl), sel(s.beta), sel(s.utils)]
-        if s.scene_table is not None:
-            out.append(s.scenes(ix))
+        if s.has_scene:
+            out.append(s.scenes(ix, generator=self.generator))
         out.append(sel(s.length))
+        if self.pose_estimation_task:            # the interactee's ground truth closes the tuple (dataset.py:1765-1781; MLD.ego_eval batch[-3:])
+            out += [sel(s.pe_motion), sel(s.transl)[:, 1:2].contiguous(), sel(s.pe_beta)]
         if self.storage == "pinned":
             out = [t.pin_memory().to(self.device, non_blocking=True) for t in out]
-        if s.scene_table is not None and not self.pose_estimation_task:
+        if s.has_scene and not self.pose_estimation_task:
             out.append([s.images[int(i)] for i in index.tolist()])
         return tuple(out)
 

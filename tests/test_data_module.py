@@ -55,7 +55,7 @@ def write_dataset(root, dataset="egobody", n=7, T=12, P=50, seed=0, with_scene=T
                 base = os.path.join(root, f"scene_{i % 3}", "scene_obj")
                 os.makedirs(base, exist_ok=True)
                 if not os.path.exists(os.path.join(base, "scene_points.npy")):
-                    np.save(os.path.join(base, "scene_points.npy"), rng.uniform(-3, 3, (P, 3)).astype(np.float32))
+                    np.save(os.path.join(base, "scene_points.npy"), rng.uniform(-3, 3, (P + 5 * (i % 3), 3)).astype(np.float32))   # ragged vertex counts
                     np.savetxt(os.path.join(base, "transform_norm.txt"), (np.eye(4) + 0.1 * rng.standard_normal((4, 4))).reshape(-1))
         if with_scene and dataset == "egobody":
             for fn, obj in ((f"map_dict_{split}.pkl", smap), (f"pcd_verts_dict_{split}.pkl", verts)):
@@ -156,3 +156,83 @@ def test_sequence_files_are_read_without_executing_them(tmp_path):
     with pytest.raises(pickle.UnpicklingError):
         D.EgoSequenceSplit(root, "train", "egobody", ("text", "interactee"), 12)
     assert not (tmp_path / "pwned").exists()
+
+
+def test_gimo_scene_clouds_are_resampled_per_access_and_jittered_in_training(tmp_path):
+    """GimoData.__getitem__ (dataset.py:2013-2033): 20000 vertices drawn WITH replacement from all vertices of the item's scene on
+    every access, / 1.03, the norm transform, and -- train split only -- N(0, 0.01) jitter.  The module does it on the device for a
+    whole batch; with the random numbers injected it must equal the per-item restatement, for scenes of different vertex counts."""
+    root = str(tmp_path / "gimo")
+    items, _ = write_dataset(root, "gimo", n=7, with_scene=True)
+    Pn = 64
+    dm = D.EgoDataModule(root, "gimo", condition=("text", "scene"), motion_length=12, device="cpu", scene_root=root, scene_points=Pn)
+    rng = np.random.default_rng(5)
+    for split in ("train", "test"):
+        s = dm.splits[split]
+        ix = torch.arange(len(s))
+        u = torch.from_numpy(rng.random((len(s), Pn)).astype(np.float32))
+        nz = torch.from_numpy(rng.standard_normal((len(s), Pn, 3)).astype(np.float32))
+        got = s.scenes(ix, draws=(u, nz)).numpy()
+        for i, name in enumerate(s.names):
+            scene = items[(split, name)]["video"][0].split("/")[-4]
+            verts = np.load(os.path.join(root, scene, "scene_obj", "scene_points.npy")).astype(np.float64)
+            tn = np.loadtxt(os.path.join(root, scene, "scene_obj", "transform_norm.txt")).reshape(4, 4)
+            tn[:3, 3] /= 1.03
+            pick = np.minimum((u[i].numpy().astype(np.float64) * len(verts)).astype(np.int64), len(verts) - 1)
+            pts = verts[pick] * (1 / 1.03)
+            pts = (tn[:3, :3] @ pts.T + tn[:3, 3:]).T
+            if split == "train":
+                pts = pts + 0.01 * nz[i].numpy()
+            np.testing.assert_allclose(got[i], pts, rtol=1e-4, atol=1e-5)
+        # the jitter is a train-split thing; every vertex of the scene can be drawn
+        if split == "test":
+            assert np.array_equal(got, s.scenes(ix, draws=(u, None)).numpy())
+    b1, b2 = dm.collate("train", torch.arange(3)), dm.collate("train", torch.arange(3))
+    assert b1[4].shape == (3, Pn, 3) and not torch.equal(b1[4], b2[4])          # a new draw per access
+    dm2 = D.EgoDataModule(root, "gimo", condition=("text", "scene"), motion_length=12, device="cpu", scene_root=root, scene_points=Pn)
+    assert torch.equal(dm2.collate("train", torch.arange(3))[4], b1[4])         # ... reproducible from the seed
+
+
+@pytest.mark.parametrize("with_pred", [False, True])
+def test_pose_estimation_batches_end_with_the_interactee_ground_truth(tmp_path, with_pred):
+    """TEST.POSE_ESTIMATION_TASK (dataset.py:1255-1256, 1333-1342, 1765-1781): the tuple ends with the interactee of the FILE --
+    motion [B,T,1,72] (normalised), transl [B,1,T,3] (normalised), betas -- in place of the image names; with EgoHMR estimates
+    (`interactee_pred`, :1300-1321) the condition slot carries the estimates (translation stays the file's) and the ground truth does not."""
+    root = str(tmp_path / "egobody")
+    items, scene = write_dataset(root, "egobody", n=5, with_scene=True)
+    mean, std = np.load(os.path.join(root, "mean.npy")), np.load(os.path.join(root, "std.npy"))
+    rng = np.random.default_rng(9)
+    if with_pred:
+        for split in ("train", "test"):
+            pred = {}
+            for (sp, name), it in items.items():
+                if sp == split:
+                    for im in it["recording_utils"]["original_imgname"]:
+                        pred[im] = {"smpl_parameters": {"global_orient": rng.standard_normal(3), "body_pose": rng.standard_normal(69) * 0.3,
+                                                        "betas": rng.standard_normal(10)}}
+            with open(os.path.join(root, f"interactee_pred_{split}.pkl"), "wb") as f:
+                pickle.dump(pred, f)
+            preds = pred if split == "test" else None
+    dm = D.EgoDataModule(root, "egobody", condition=("text", "scene", "interactee"), motion_length=12, device="cpu", scene_root=root,
+                         pose_estimation_task=True, interactee_pred=with_pred)
+    s = dm.splits["test"]
+    b = dm.collate("test", torch.arange(len(s)))
+    assert len(b) == 9 and all(torch.is_tensor(t) for t in b)
+    motion, transl, beta, utils, sc, length, g_motion, g_transl, g_beta = b
+    assert g_motion.shape == (len(s), 12, 1, 72) and g_transl.shape == (len(s), 1, 12, 3) and g_beta.shape == (len(s), 12, 1, 10)
+    for i, name in enumerate(s.names):
+        want = reference_item(items[("test", name)], mean, std, 12, "egobody")
+        np.testing.assert_allclose(g_motion[i, :, 0].numpy(), want["motion"][:, 1], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(g_transl[i, 0].numpy(), want["transl"][1], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(g_beta[i, :, 0].numpy(), want["beta"][1], rtol=1e-6)
+        np.testing.assert_allclose(transl[i].numpy(), want["transl"], rtol=1e-5, atol=1e-6)           # translation: never from the estimates
+        np.testing.assert_allclose(motion[i, :, 0].numpy(), want["motion"][:, 0], rtol=1e-5, atol=1e-6)
+        if not with_pred:
+            np.testing.assert_allclose(motion[i, :, 1].numpy(), want["motion"][:, 1], rtol=1e-5, atol=1e-6)
+        else:
+            L = int(length[i])
+            imgs = items[("test", name)]["recording_utils"]["original_imgname"]
+            est = np.stack([np.concatenate([preds[im]["smpl_parameters"]["global_orient"], preds[im]["smpl_parameters"]["body_pose"]]) for im in imgs])
+            np.testing.assert_allclose(motion[i, :L, 1].numpy(), (est - mean[0, :72]) / std[0, :72], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(beta[i, 1, :L].numpy(), np.stack([preds[im]["smpl_parameters"]["betas"] for im in imgs]), rtol=1e-5)
+    assert len(s.item(0)) == 9

@@ -384,6 +384,58 @@ def test_data_module_feeds_training_and_eval(dev, tmp_path):
     assert np.isfinite(got["MPJPE"]) and got["count_seq"] > 0
 
 
+def test_data_module_pose_estimation_and_gimo_on_device(dev, tmp_path):
+    """(i) TEST.POSE_ESTIMATION_TASK on files: EgoDataModule batches end with the interactee's ground truth (dataset.py:1765-1781) and
+    MLD.test_step consumes them (batch[:-3] / batch[-3:], mld.py:1119-1131) -- with and without EgoHMR estimates as the condition.
+    (ii) GIMO: the scene vertices live on the device, every batch draws a new 20000-point sample (+ jitter in training,
+    dataset.py:2013-2033), and a stage-2 training step runs on those batches."""
+    import pickle
+    from test_data_module import write_dataset
+    from seeme_amd import data as D
+    from seeme_amd.config import parse_config
+    from seeme_amd.mld import MLD
+    from seeme_amd.smpl import SMPL
+    root = str(tmp_path / "egobody")
+    items, _ = write_dataset(root, "egobody", n=6, T=12, P=64, full_every=2)
+    rng = np.random.default_rng(1)
+    pred = {im: {"smpl_parameters": {"global_orient": rng.standard_normal(3), "body_pose": 0.3 * rng.standard_normal(69), "betas": rng.standard_normal(10)}}
+            for (sp, _n), it in items.items() if sp == "test" for im in it["recording_utils"]["original_imgname"]}
+    with open(os.path.join(root, "interactee_pred_test.pkl"), "wb") as f:
+        pickle.dump(pred, f)
+    cfg = parse_config(os.path.join(REPO, "configs", "config_mld_scene.yaml"))
+    cfg.model.scheduler.num_inference_timesteps = 5
+    cfg.TEST.POSE_ESTIMATION_TASK = True
+    for with_pred in (False, True):
+        dm = D.EgoDataModule(root, "egobody", condition=("text", "scene", "interactee"), motion_length=12, device=dev, scene_root=root,
+                             pose_estimation_task=True, interactee_pred=with_pred, splits=("test",))
+        model = MLD(cfg, dm, smpl_model=SMPL.synthetic(1234))
+        load_recipe_(model.vae), load_recipe_(model.denoiser), load_recipe_(model.proscene.scene_enc)
+        model = model.to(dev).eval()
+        model.EgoMetric.reset()
+        for b in dm.iterate("test", 3):
+            assert len(b) == 9 and b[6].shape[1:] == (12, 1, 72) and b[7].shape[1:] == (1, 12, 3)
+            out = model.test_step(b)
+            assert out.shape[1:] == (12, 24, 3) and torch.isfinite(out).all()
+        got = model.EgoMetric.compute()
+        assert np.isfinite(got["mpjpe_interactee"]) and got["mpjpe_interactee"] >= 0
+    # ---- GIMO
+    groot = str(tmp_path / "gimo")
+    write_dataset(groot, "gimo", n=6, T=12, P=300, full_every=2)
+    dm = D.EgoDataModule(groot, "gimo", condition=("text", "scene"), motion_length=12, device=dev, scene_root=groot, scene_points=2000)
+    tr = dm.splits["train"]
+    assert tr.scene_flat.is_cuda and tr.scene_table is None
+    b1, b2 = dm.batch(4, idx=0, split="train"), dm.batch(4, idx=0, split="train")
+    assert b1[4].shape == (4, 2000, 3) and b1[4].is_cuda and not torch.equal(b1[4], b2[4]) and torch.equal(b1[0], b2[0])
+    cfg = parse_config(os.path.join(REPO, "configs", "config_mld_gimo.yaml"))
+    model = MLD(cfg, dm, smpl_model=SMPL.synthetic(1234))
+    load_recipe_(model.vae), load_recipe_(model.denoiser), load_recipe_(model.proscene.scene_enc)
+    model = model.to(dev).train()
+    for it in range(2):
+        loss = model.training_step(dm.batch(4, idx=it, split="train"))
+        model.optimizer_step(loss)
+        assert np.isfinite(float(loss))
+
+
 @pytest.mark.parametrize("cfg_name,B", [("config_mld_scene.yaml", 5), ("config_mld_gimo.yaml", 3), ("config_mld_egobody.yaml", 70)])
 def test_stage2_glue_matches_autograd_path(dev, cfg_name, B):
     """stage2_glue (hand-written HIP forward + backward of rsample / add_noise / time MLP / output_scene / condition and
