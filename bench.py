@@ -338,6 +338,13 @@ def train_mode(args, dev, rank, world, backend, dist_on):
         "collective_backend": (backend if dist_on else None),
         "grad_bucket_bytes": (int(model.grad_bucket().flat.numel() * 4) if model.grad_bucket() is not None else None),
     }
+    gb = model.grad_bucket()
+    if gb is not None and gb.early_span is not None:
+        # exchanged asynchronously from the middle of the backward (every chain matrix but in_proj), the rest after it
+        eb = int((gb.early_span[1] - gb.early_span[0]) * 4)
+        res["grad_exchange"] = {"overlapped_with_backward_bytes": eb if (gb.overlap and world > 1) else 0,
+                                "after_backward_bytes": int(gb.flat.numel() * 4) - (eb if (gb.overlap and world > 1) else 0),
+                                "note": "phases_ms.allreduce is what the step still waits for after the backward"}
     if not args.graph:
         ph = lambda a, b: round(float(np.mean([e[a].elapsed_time(e[b]) for e in evs])), 4)
         res["phases_ms"] = {"backward": ph(0, 1), "allreduce": ph(1, 2), "adamw": ph(2, 3)}

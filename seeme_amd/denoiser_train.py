@@ -156,6 +156,12 @@ class TrainPack:
         vec(1, fin, 256)                           # encoder.norm.weight / bias
         vec(2, fin + 256, 256)
         self.gflat_numel, self._vec0, self._spans = off, vec0, spans
+        # [end of the in_proj block, start of the vectors): no other part of the backward adds to these gradients (in_proj's K | V rows
+        # and bias also collect the condition / time-table contributions) -- distributed.GradBucket exchanges it early
+        name0, ls0, off0, Nn0, K0 = self.mat_blocks[0]
+        assert name0 == "inp" and off0 == 0
+        self.early_span = (len(ls0) * Nn0 * K0, vec0)
+        self.bucket = None
         self.gather_idx = torch.tensor(gather, device=dev, dtype=torch.int64)
         self.dx0_span = (fin + 512, fin + 768)
         self.bound, self._attached = False, False
@@ -205,6 +211,8 @@ class TrainPack:
                     "seeme_den_vecgrad")
             if self._attached:                                 # GradBucket.prepare() made .grad these very views
                 self._attached = False
+                if self.bucket is not None:
+                    self.bucket.allreduce_early()              # the matrices other than in_proj are final: exchange them now
                 return
             for p, v in zip(self.params, self.grad_views):     # a backward outside the bucket's step: same contract as below
                 if p.requires_grad:

@@ -57,7 +57,13 @@ class GradBucket:
 
     Layout: [the chain's gradient block of ``pack`` (denoiser_train.TrainPack), if any | every other trainable
     parameter in ``parameters`` order].  ``prepare()`` before each backward re-attaches the views and zeroes the part
-    autograd accumulates into; gradient accumulation over several backwards is not what this object is for."""
+    autograd accumulates into; gradient accumulation over several backwards is not what this object is for.
+
+    Overlap with the backward (what DDP's bucketed hooks give the reference, train.py:127-131): ``early_span`` is the part of the
+    chain block that is FINAL as soon as the chain's weight-gradient kernels have run -- every matrix except in_proj (whose K | V
+    rows also collect the condition / time-table contributions later in the backward) -- 18 of the 31.6 MB.  ``allreduce_early()``
+    (called by TrainPack.reduce_into_grads) starts its exchange asynchronously right there, on the collective's own stream, while the
+    rest of the backward runs; ``allreduce()`` exchanges what is left and waits for both."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], pack=None):
         self.params = [p for p in params if p.requires_grad]
@@ -89,12 +95,19 @@ class GradBucket:
                 if i != 0 and p.requires_grad:
                     self.views[id(p)] = pack.grad_views[i]
         self._pack_key = None if pack is None else id(pack)
+        self.early_span = None
+        self._early = None
+        self.overlap = os.environ.get("SEEME_GRAD_OVERLAP", "1") != "0"
+        if pack is not None and getattr(pack, "early_span", None) is not None:
+            self.early_span = tuple(int(v) for v in pack.early_span)
+            pack.bucket = self
 
     def matches(self, pack) -> bool:
         return self._pack_key == (None if pack is None else id(pack))
 
     def prepare(self):
         """Before backward: ``.grad`` = the views; zero what autograd adds into (the chain block is overwritten)."""
+        assert self._early is None, "GradBucket: the previous step's early exchange was never completed (allreduce() not called)"
         self.flat[self.n_pack:].zero_()
         for p in self.params:
             v = self.views[id(p)]
@@ -103,15 +116,38 @@ class GradBucket:
         if self.pack is not None:
             self.pack._attached = True
 
+    def allreduce_early(self, average: bool = True) -> int:
+        """Start the mean all-reduce of ``early_span`` now, asynchronously (it is final; see the class docstring).  Returns the
+        number of elements in flight (0: single process, no early span, or overlap switched off)."""
+        rank, ws = world()
+        if ws == 1 or self.early_span is None or not self.overlap or self._early is not None:
+            return 0
+        if self.flat.is_cuda and torch.cuda.is_current_stream_capturing():
+            return 0
+        lo, hi = self.early_span
+        view = self.flat[lo:hi]
+        avg_op = average and dist.get_backend() == "nccl"
+        work = dist.all_reduce(view, op=dist.ReduceOp.AVG if avg_op else dist.ReduceOp.SUM, async_op=True)
+        self._early = (work, view, average and not avg_op)
+        return int(view.numel())
+
     def allreduce(self, average: bool = True) -> int:
         rank, ws = world()
         if ws > 1:
-            if average and dist.get_backend() == "nccl":
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
-            else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-                if average:
-                    self.flat.div_(ws)
+            n = int(self.flat.numel())
+            spans = [(0, n)] if self._early is None else [(0, self.early_span[0]), (self.early_span[1], n)]
+            avg_op = average and dist.get_backend() == "nccl"
+            for a, b in spans:
+                if b > a:
+                    dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.AVG if avg_op else dist.ReduceOp.SUM)
+                    if average and not avg_op:
+                        self.flat[a:b].div_(ws)
+            if self._early is not None:
+                work, view, div = self._early
+                work.wait()                               # (NCCL: the current stream waits for the collective's stream; the host does not)
+                if div:
+                    view.div_(ws)
+                self._early = None
         return int(self.flat.numel())
 
 

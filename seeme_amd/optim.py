@@ -89,6 +89,14 @@ class FusedAdamWStep:
             self._dev_lr[id(group)] = float(group["lr"])
         return sc
 
+    def _refresh_device_step(self, group, shared):
+        """The device-side {step, lr} tensor is never dropped once it exists: a hipGraph captured by MLD.capture_training_step has
+        its ADDRESS baked in, and a freed tensor's memory may be handed to someone else while replays still add to it.  After a
+        host-side step (or load_state_dict) the count is rewritten in place instead."""
+        sc = self._dev_scalars.get(id(group))
+        if sc is not None and not torch.cuda.is_current_stream_capturing():
+            sc[0].fill_(float(shared))
+
     def sync_lr(self):
         """Push a learning rate the LR scheduler edited to the device-side scalars (before replaying a captured step)."""
         for group in self.opt.param_groups:
@@ -133,7 +141,7 @@ class FusedAdamWStep:
                 self._shared[id(group)] = shared
                 for p in params:
                     self.opt.state[p]["step"] = shared
-                self._dev_scalars.pop(id(group), None)
+                self._refresh_device_step(group, shared)
             self._tables(params)
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in params]
             gp = self._grad_pointers(grads, params[0].device)
@@ -150,7 +158,7 @@ class FusedAdamWStep:
             else:
                 step = float(shared) + 1.0
                 shared.fill_(step)
-                self._dev_scalars.pop(id(group), None)    # the device-side count (if any) is stale now
+                self._refresh_device_step(group, shared)  # the device-side count (if any) follows the host's
                 L.check(L.lib().seeme_adamw_step(self._chunks.data_ptr(), self._n_chunks, self._p.data_ptr(), gp.data_ptr(),
                                                  self._m.data_ptr(), self._v.data_ptr(), float(group["lr"]), float(b1), float(b2),
                                                  float(group["eps"]), float(group["weight_decay"]), float(step),

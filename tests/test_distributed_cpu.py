@@ -48,12 +48,32 @@ def _worker(rank, ws, port, q):
     zeroed = float(bucket.flat.abs().max())
     lin2(x).sum().backward()
     bucket.allreduce()
+    # 2c) overlap with the backward: the part of the buffer that is final early is exchanged asynchronously while "the rest of the
+    # backward" still writes the other parts; allreduce() then exchanges those and completes both
+    big = [torch.nn.Parameter(torch.zeros(40)), torch.nn.Parameter(torch.zeros(7))]
+    b3 = D.GradBucket(big)
+    b3.early_span = (10, 30)
+    b3.prepare()
+    b3.flat[10:30] = torch.arange(20.0) * (rank + 1)       # final
+    started = b3.allreduce_early()
+    b3.flat[:10] = float(rank + 1)                          # written while the early exchange is in flight
+    b3.flat[30:] = -2.0 * (rank + 1)
+    b3.allreduce()
+    early_ok = (started == 20 and b3._early is None and torch.allclose(b3.flat[10:30], torch.arange(20.0) * 1.5)
+                and torch.allclose(b3.flat[:10], torch.full((10,), 1.5)) and torch.allclose(b3.flat[30:], torch.full((17,), -3.0))
+                and big[1].grad.data_ptr() == b3.flat[40:].data_ptr())
+    b3.prepare()
+    b3.overlap = False                                     # switched off: one exchange of everything, same result
+    b3.flat[:] = float(rank + 1)
+    early_ok = early_ok and b3.allreduce_early() == 0
+    b3.allreduce()
+    early_ok = early_ok and torch.allclose(b3.flat, torch.full((47,), 1.5))
     # 3) metric sums
     s = D.reduce_sums(torch.tensor([1.0 + rank, 10.0, 1.0], dtype=torch.float64))
     # plain lists, not tensors: a tensor travels as a file descriptor served by THIS process, and the parent may come for
     # it after this process has exited (FileNotFoundError on the resource-sharer socket, seen once in ~20 runs)
     q.put((rank, all_ranges, n, lin.weight.grad.tolist(), extra.grad.tolist(), s.tolist(), nb, zeroed, lin2.weight.grad.tolist(),
-           lin2.bias.grad.tolist()))
+           lin2.bias.grad.tolist(), bool(early_ok)))
     dist.destroy_process_group()
 
 
@@ -80,6 +100,7 @@ def test_world2_gloo():
         assert torch.allclose(torch.tensor(r[5], dtype=torch.float64), torch.tensor([3.0, 20.0, 2.0], dtype=torch.float64))
         assert r[6] == 8 * 4 + 4 and r[7] == 0.0
         assert torch.allclose(torch.tensor(r[8]), torch.full((4, 8), 4.5)) and torch.allclose(torch.tensor(r[9]), torch.full((4,), 3.0))
+        assert r[10]
 
 
 def test_single_process_is_identity():

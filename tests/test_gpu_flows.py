@@ -649,3 +649,51 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(dev, mode_args, metric_word):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["collective_backend"] == "gloo" and d["scaling"] == "weak"
     assert metric_word in d["metric"] and d["value"] > 0 and d["steps"] == 2
+
+
+def test_cfg5_ddpm1000_at_its_own_size(dev):
+    """BASELINE configs[4]: 1000-step DDPM (ancestral sampling, configs/modules_novae/scheduler.yaml:16-26 of the reference;
+    mld.py:432-511), 4096 sequences over 8 GPUs = 512 per GPU, 16-bit weights, hipGraph-captured.
+    (i) bench.py --scheduler ddpm --batch 512 --graph runs the per-GPU share at its own size and prints the contract line;
+    (ii) what 1000 CHAINED steps do to the 16-bit weight image: on B = 32 sequences with injected initial latents, condition noise
+    and step noise [1000,32,256] the fp16 image's final latent, decoded features and MPJPE against the fp32 image's (measured and
+    printed; bounded loosely -- the ancestral noise re-injected at every step dominates the state, so rounding does not build up)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--scheduler", "ddpm", "--batch", "512", "--graph", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-parity-check"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "1000 DDPM steps" in d["metric"] and d["config"]["batch_per_gpu"] == 512 and d["config"]["ddim_steps"] == 1000
+    assert d["value"] > 0 and d["roofline"]["ms_per_launch"] > 0
+    print("cfg5 per-GPU share:", d["value"], "seqs/s,", d["ms_per_step"], "ms per pass of 512 sequences, sampling kernel", d["roofline"]["ms_per_launch"], "ms")
+
+    from seeme_amd.mld import EgoMetrics
+    def mut(cfg):
+        cfg.model.scheduler.target = "seeme_amd.schedulers.DDPMScheduler"
+        cfg.model.scheduler.num_inference_timesteps = 1000
+        cfg.model.scheduler.params = {"num_train_timesteps": 1000, "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear",
+                                      "variance_type": "fixed_small", "clip_sample": False}
+    model, dm, cfg = _mld(dev, "config_mld_egobody.yaml", T=196, mutate=mut)
+    model.eval()
+    B = 32
+    batch = dm.batch(B, idx=3)
+    g = torch.Generator().manual_seed(77)
+    lat, eps = torch.randn(B, 1, 256, generator=g).to(dev), torch.randn(1, B, 256, generator=g).to(dev)
+    noise = torch.randn(1000, B, 256, generator=g).to(dev)
+    out = {}
+    for wd in ("fp32", "fp16", "bf16"):
+        model.denoiser.weight_dtype = wd
+        rs = model.ego_eval(batch, latents=lat, cond_noise=eps, step_noise=noise)
+        assert model.denoiser.cluster_status()[0] == 0
+        out[wd] = (rs["lat_rst"] if "lat_rst" in rs else None, rs["m_rst"], rs["joints_rst"],
+                   EgoMetrics.per_sequence(rs["joints_rst"], rs["joints_ref"], rs["lengths"])["MPJPE"].double().mean().item())
+    for wd in ("fp16", "bf16"):
+        fe = rel_err(_np(out[wd][1]), _np(out["fp32"][1]))
+        j2j = float((out[wd][2] - out["fp32"][2]).norm(dim=-1).mean() * 1000.0)
+        print(f"1000 DDPM steps, {wd} image vs fp32 image: decoded features rel err {fe:.3e}, joint-to-joint {j2j:.3f} mm, "
+              f"MPJPE {out[wd][3]:.6f} vs {out['fp32'][3]:.6f} mm (delta {abs(out[wd][3] - out['fp32'][3]):.2e})")
+        assert np.isfinite(fe) and fe < (2e-2 if wd == "fp16" else 1e-1)
+        assert abs(out[wd][3] - out["fp32"][3]) < (1e-2 if wd == "fp16" else 5e-2)
