@@ -191,6 +191,44 @@ __device__ __forceinline__ void cl_store_granule(unsigned long long* g, unsigned
 }
 __device__ __forceinline__ unsigned cl_tags_ok(const u32x4& a, unsigned epoch) { return (unsigned)(a.y == epoch) & (unsigned)(a.w == epoch); }   // (no short-circuit branches)
 
+// The next layer's small operands -> the other half of the staging buffer, through registers: only what THIS CU reads (its slices of the
+// in_proj / skip / linear1 biases, the LayerNorm and bias vectors of the replicated stages, the time token's K | V' and the ffn AdaLN rows, the
+// condition token's K | V', the tabulated ca term): 22-23 pieces of at most 1 KiB = 17.9 KB at C = 8, three per wave: one requested at the top
+// of each of the phases B, D and F and stored to LDS at its end, so that the load's latency passes behind the phase.  (As 36 KB of LDS-DMA -- stage_dma, what k_den_sample
+// does -- the same operands cost this kernel 1.9 k cycles per layer: LDS-DMA moves ~40 GB/s per CU, and here nothing overlaps it.)
+template <int C>
+struct ClStage {
+    float4 r; int dst, n4;        // ONE piece per wave and phase (k = 0 in phase B, 1 in D, 2 in F): 4 registers live across a phase
+    __device__ __forceinline__ void load(int k, int wave, int lane, const float* __restrict__ vpg, const DenLayerOff* __restrict__ L,
+                                         const float* __restrict__ tt_row, int l, const SeemeSampleArgs& A, int b, int c, int ca_r, int ca_R) {
+        typedef ClG<C> G;
+        constexpr int NL1 = G::NB > 256 ? G::NB / 256 : 1, NSEG = 21 + NL1;
+        static_assert(NSEG <= 24, "three pieces per wave");
+        const float* vb = vpg + L->skip_b;
+        const int o_in = (int)(L->in_b - L->skip_b);
+        const int i = wave + 8 * k;
+        const float* src = vb; int d = 0, n = 0;
+        if (i == 0) { d = c * G::S; src = vb + d; n = G::S / 4; }
+        else if (i <= 3) { d = o_in + (i - 1) * 256 + c * G::S; src = vb + d; n = G::S / 4; }
+        else if (i <= 13) {
+            const int64_t f = i == 4 ? L->n1w : i == 5 ? L->n1b : i == 6 ? L->l2b : i == 7 ? L->n2w : i == 8 ? L->n2b : i == 9 ? L->f1b
+                            : i == 10 ? L->f2b : i == 11 ? L->fsnw : i == 12 ? L->fsnb : L->fo_b;
+            d = (int)(f - L->skip_b); src = vb + d; n = i == 9 ? FF_D / 4 : 64;
+        }
+        else if (i <= 15) { src = tt_row + l * 512 + (i - 14) * 256; d = VP_LAYER + (i - 14) * 256; n = 64; }                 // time token K | V'
+        else if (i <= 17) { src = tt_row + 2560 + l * 1024 + 512 + (i - 16) * 256; d = VP_LAYER + 1024 + (i - 16) * 256; n = 64; }   // ffn AdaLN scale | shift
+        else if (i <= 19) { src = A.ctab + (size_t)b * SEEME_CROW + l * 512 + (i - 18) * 256; d = VP_LAYER + STG_TT + (i - 18) * 256; n = 64; }
+        else if (i == 20) { src = A.catab + (((size_t)b * ca_R + ca_r) * SEEME_DEN_NL + l) * 256; d = VP_LAYER + STG_TT + 1024; n = 64; }
+        else if (i < NSEG) { d = (int)(L->l1b - L->skip_b) + c * G::NB + (i - 21) * 256; src = vb + d; n = G::NB >= 256 ? 64 : G::NB / 4; }
+        dst = d; n4 = n;
+        r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < n) r = *reinterpret_cast<const float4*>(src + 4 * lane);
+    }
+    __device__ __forceinline__ void store(int lane, float* __restrict__ stg) const {
+        if (lane < n4) *reinterpret_cast<float4*>(stg + dst + 4 * lane) = r;
+    }
+};
+
 template <typename WT, int C>
 __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -391,11 +429,13 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
             __syncthreads(); DEN_DBG(0);
 
             // ================= B: linear1 + ReLU, column-split =================
+            // (a piece of the next layer's small operands is requested here and stored to the other half of the staging buffer at the end
+            //  of the phase -- BEFORE the deferred re-fills: vmcnt is in order, and the store must not wait for them)
+            ClStage<C> nxt;
+            const float* const tt_next = A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW;
+            const int ca_next = A.trow_per_sample ? 0 : (ln == 0 ? step_next : step);
+            nxt.load(0, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
             cl_refills<WT, C, G::U_A + A_DEF0>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2 * G::TA - A_DEF0>{});   // slots of stage A
-            // (the next layer's operands leave for the other half of the staging buffer here: every wave consumes F units,
-            //  requested later than these copies, before the barrier that closes the layer)
-            stage_dma<1, false, 0, 0>(wave, lane, STG + (cur ^ 1) * stg_sz, vp, Ln, A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW, ln, A, b, N,
-                                      A.trow_per_sample ? 0 : (ln == 0 ? step_next : step), ca_R);
             {
                 f32x4 acc[G::TB];
                 cl_zero<G::TB>(acc);
@@ -408,6 +448,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                     }
                 }
             }
+            nxt.store(lane, STG + (cur ^ 1) * stg_sz);
             __syncthreads(); DEN_DBG(0);
 
             // ================= C: linear2, row-split -> X2 =================
@@ -453,6 +494,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
             __syncthreads(); DEN_DBG(0);
 
             // ================= D: ffn.linear1 + GELU (replicated) =================
+            nxt.load(1, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
             cl_refills<WT, C, G::U_C + C_INL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB - C_INL>{});       // slots of stage C
             {
                 f32x4 acc[1];
@@ -463,6 +505,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                     cl_put1<WT>(XH, j, fast_gelu(cl_out<WT>(acc[0]) + v_f1b[j]));
                 }
             }
+            nxt.store(lane, STG + (cur ^ 1) * stg_sz);
             __syncthreads(); DEN_DBG(0);
             // ================= E: ffn.linear2 -> LayerNorm, AdaLN, SiLU (replicated) =================
             {
@@ -479,6 +522,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
             }
             __syncthreads(); DEN_DBG(0);
             // ================= F: ffn.proj_out.out_layers + residual (replicated); writes the next layer's input =================
+            nxt.load(2, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
             {
                 f32x4 acc[2];
                 cl_zero<2>(acc);
@@ -491,6 +535,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                     if (l < 2) cl_put1<WT>(SKF + 512 * l, n, xn);                      // xs.append(x) (cross_attention.py:70-72)
                 }
             }
+            nxt.store(lane, STG + (cur ^ 1) * stg_sz);
             __syncthreads(); DEN_DBG(0);
             if (l + 1 < SEEME_DEN_NL) {
                 if (epi && !nskip) xr = ld4(RES + 4 * lane);                          // residual of the next layer's attention

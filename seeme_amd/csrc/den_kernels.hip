@@ -155,7 +155,11 @@ __device__ __forceinline__ void den_dbg(int mode) {   // 0: stamp, 1: arm (reset
     if (mode == 1) { cnt = 0; armed = 1; }
     else if (mode == 2) { armed = 0; }
     else if (mode == 0) { if (armed && cnt < 511) { buf[cnt] = __builtin_readcyclecounter(); cnt = cnt + 1; } }
-    else { for (int i = 0; i < cnt; ++i) den_dbg_times[i + 1] = buf[i]; den_dbg_times[0] = (unsigned long long)cnt; }
+    else {   // (a launch of fewer than 3 steps never armed: cnt is then whatever the LDS held)
+        const int n = (armed == 0 && cnt >= 0 && cnt <= 511) ? cnt : 0;
+        for (int i = 0; i < n; ++i) den_dbg_times[i + 1] = buf[i];
+        den_dbg_times[0] = (unsigned long long)n;
+    }
 }
 #define DEN_DBG(m) den_dbg(m)
 #else
