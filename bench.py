@@ -160,8 +160,22 @@ def cpu_baseline(B, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt > budget_s:
             break
+    # BASELINE configs[0] (the reference's own CPU-runnable case): VAE reconstruct, B = 4 random T = 196 sequences
+    m4, l4 = motion[:4], [T_FRAMES] * 4
+
+    def rec():
+        mu4, _ = OT.vae_encode(Pv, m4, l4)
+        OT.vae_decode(Pv, mu4, l4)
+
+    rec()
+    n1, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < 2.0:
+        rec()
+        n1 += 4
+    cfg1 = {"value": round(n1 / (time.perf_counter() - t1), 2), "unit": "seqs/s",
+            "sample": f"{n1} sequences: config_vae_egobody VAE reconstruct (encode -> decode(mu)), passes of B=4, T=196, F={NFEATS}, {best} threads"}
     torch.set_num_threads(prev)
-    return {"value": round(n / dt, 3), "unit": "seqs/s", "cores": best, "kind": "port",
+    return {"value": round(n / dt, 3), "unit": "seqs/s", "cores": best, "kind": "port", "cfg1_vae_reconstruct": cfg1,
             "sample": f"{n} sequences (passes of B={Bc}, T=196, 50 DDIM steps) in {dt:.1f}s, PyTorch-CPU fp32 oracle, "
                       f"{best} threads of {ncpu} usable logical CPUs (trial s: "
                       + ", ".join(f"{k}t {v:.2f}" for k, v in trials.items()) + ")"}
@@ -573,6 +587,18 @@ def main():
                 res["parity_mode"] = {"dtype": "f32", "value": round(B * args.steps / (time.perf_counter() - tp), 2), "unit": "seqs/s"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(B)
+            # the GPU side of BASELINE configs[0] (VAE reconstruct, B = 4), fp32 parity path, beside its CPU leg
+            pv = build_models(dev, "fp32", "fp32")[0]
+            m4, l4 = motion[:4].contiguous(), [T_FRAMES] * 4
+            for _ in range(3):
+                pv.decode(pv.encode_dist(m4, l4)[0].unsqueeze(0), l4)
+            torch.cuda.synchronize()
+            tq, nq = time.perf_counter(), 50
+            for _ in range(nq):
+                pv.decode(pv.encode_dist(m4, l4)[0].unsqueeze(0), l4)
+            torch.cuda.synchronize()
+            res["cfg1_vae_reconstruct"] = {"value": round(4 * nq / (time.perf_counter() - tq), 1), "unit": "seqs/s", "dtype": "f32",
+                                           "on": "config_vae_egobody VAE reconstruct (encode -> decode(mu)), B=4, T=196, F=132, fp32 parity path"}
         print(json.dumps(res), flush=True)
     if dist_on:
         dist.destroy_process_group()

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, load_golden, rel_err
+from conftest import REPO, elem_err, load_golden, rel_err
 from oracle import mld_oracle as O
 from seeme_amd.weights_recipe import load_recipe_, recipe_state_dict
 from seeme_amd import shapes
@@ -108,10 +108,11 @@ def test_vae_golden(dev, name, F):
     torch.cuda.synchronize()
     assert rel_err(dist.loc.cpu().numpy(), g["mu"]) < TOL_F32
     assert rel_err(dist.scale.cpu().numpy(), g["std"]) < TOL_F32
+    assert elem_err(dist.loc.cpu().numpy(), g["mu"]) < TOL_F32 and elem_err(dist.scale.cpu().numpy(), g["std"]) < TOL_F32   # element by element
     dec = vae.decode(torch.from_numpy(g["mu"]).to(dev), lengths)
     torch.cuda.synchronize()
     assert dec.shape == g["decoded"].shape
-    assert rel_err(dec.cpu().numpy(), g["decoded"]) < TOL_F32
+    assert rel_err(dec.cpu().numpy(), g["decoded"]) < TOL_F32 and elem_err(dec.cpu().numpy(), g["decoded"]) < TOL_F32
 
 
 def test_vae_vs_oracle_bench_shape(dev):
@@ -150,9 +151,9 @@ def test_denoiser_golden(dev, N):
     s, c = torch.from_numpy(g["sample"]).to(dev), torch.from_numpy(g["cond"]).to(dev)
     for t in (981, 501, 1):
         y = den(sample=s, timestep=torch.tensor(t), encoder_hidden_states=c)[0]
-        assert rel_err(y.cpu().numpy(), g[f"out_t{t}"]) < TOL_F32
+        assert rel_err(y.cpu().numpy(), g[f"out_t{t}"]) < TOL_F32 and elem_err(y.cpu().numpy(), g[f"out_t{t}"]) < TOL_F32
     y = den(sample=s, timestep=torch.from_numpy(g["tvec"]).to(dev), encoder_hidden_states=c)[0]
-    assert rel_err(y.cpu().numpy(), g["out_tvec"]) < TOL_F32
+    assert rel_err(y.cpu().numpy(), g["out_tvec"]) < TOL_F32 and elem_err(y.cpu().numpy(), g["out_tvec"]) < TOL_F32
 
 
 @pytest.mark.parametrize("wd,tol", [("bf16", TOL_BF16W), ("fp16", 4e-3)])
@@ -190,6 +191,7 @@ def test_ddim_loop_golden(dev):
     out = den.sample_loop(torch.from_numpy(g["latents"]).to(dev), torch.from_numpy(g["cond_bf"]).to(dev), sch)
     assert out.shape == g["out"].shape
     assert rel_err(out.cpu().numpy(), g["out"]) < 5e-4   # 50 chained steps
+    assert elem_err(out.cpu().numpy(), g["out"]) < 5e-4
 
 
 def test_ddim_loop_cfg_golden(dev):
@@ -925,9 +927,9 @@ def test_cluster_sampler_vs_reference_fixtures(dev, Cc):
     s, c = torch.from_numpy(g["sample"]).to(dev), torch.from_numpy(g["cond"]).to(dev)
     for t in (981, 501, 1):
         y = den(sample=s, timestep=torch.tensor(t), encoder_hidden_states=c)[0]
-        assert rel_err(y.cpu().numpy(), g[f"out_t{t}"]) < TOL_F32
+        assert rel_err(y.cpu().numpy(), g[f"out_t{t}"]) < TOL_F32 and elem_err(y.cpu().numpy(), g[f"out_t{t}"]) < TOL_F32
     y = den(sample=s, timestep=torch.from_numpy(g["tvec"]).to(dev), encoder_hidden_states=c)[0]
-    assert rel_err(y.cpu().numpy(), g["out_tvec"]) < TOL_F32
+    assert rel_err(y.cpu().numpy(), g["out_tvec"]) < TOL_F32 and elem_err(y.cpu().numpy(), g["out_tvec"]) < TOL_F32
     gl = load_golden("ddim50_N1_B3.npz")
     sch = _sched()
     sch.set_timesteps(int(gl["steps"]))
