@@ -518,6 +518,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert os.environ.get("SEEME_DEBUG_NOCHECK") or torch.isfinite(out).all()   # (debug timing builds produce garbage)
+    for _, d, _ in models:                                  # no cluster of the sampling kernel may have given up waiting for a peer
+        code, _local = d.cluster_status()
+        assert code == 0, f"k_den_cluster: exchange timed out (code {code}): the results of this run are invalid"
 
     # dominant kernel: the persistent DDIM kernel
     loop_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
