@@ -215,7 +215,7 @@ typedef struct {
 int seeme_denoiser_sample(const SeemeDenoiserWeights* w, const SeemeSampleArgs* a, void* stream);
 
 /* ---- the same loop with ONE SAMPLE SPLIT OVER C WORKGROUPS (csrc/den_cluster.inc.hip; MLD._diffusion_reverse, mld.py:467-497, at
- * batch sizes that leave most of the chip idle: B x C <= 256).  One attention head, one condition token (catab), no CFG.
+ * batch sizes that leave most of the chip idle: B x C <= 256).  One attention head, one or two condition tokens, no CFG.
  *   wgc : the cluster weight image [layer 5][CU C][unit][wave 8][load][lane 64][16 B], packed by the host
  *         (seeme_amd/mld_denoiser.py, geometry from seeme_den_cluster_layout); the skip linears of layers 3, 4 are folded
  *         into that layer's in_proj;
@@ -232,11 +232,13 @@ typedef struct {
     int placement;
     int flags;
     void* xchg; size_t xchg_bytes;
+    int query;                           /* 0: image packed for ONE condition token (ca term from seeme_denoiser_ca_tables); 1: for two
+                                          * (units of ca_block.query / proj_out included, one more exchange per layer) */
 } SeemeDenCluster;
 size_t seeme_den_cluster_xchg_bytes(int B, int C);
-/* out[0] units per (layer, CU), [1] bytes per unit, [2] image bytes, [3] wave-loads per unit, [4] k per wave-load,
- * [5..11] first unit of stage A (x half), A (skip half), B, C, D, E, F */
-int seeme_den_cluster_layout(int C, int wdtype, int64_t* out, int cap);
+/* out[0] units per (layer, CU) incl. padding, [1] bytes per unit, [2] image bytes, [3] wave-loads per unit, [4] k per wave-load,
+ * [5..11] first unit of stage A (x half), A (skip half), B, C, D, E, F, [12] of G (ca query), [13] of H (ca proj_out) (-1 when query = 0) */
+int seeme_den_cluster_layout(int C, int wdtype, int query, int64_t* out, int cap);
 int seeme_denoiser_sample_cluster(const SeemeDenoiserWeights* w, const SeemeDenCluster* cl, const SeemeSampleArgs* a, void* stream);
 
 /* ---- stage-2 training (MLD._diffusion_process, mld.py:582-631, and the backward of MldDenoiser.forward) ----

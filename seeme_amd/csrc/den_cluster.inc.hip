@@ -48,15 +48,20 @@ template <typename WT> struct ClW {
     static constexpr int RU = WT::MFMA ? 4 : 2;        // units in the register ring (32 x 16 B per lane either way)
     static constexpr unsigned UNIT_BYTES = 8u * UL * 1024u;
 };
-template <int C> struct ClG {
+template <int C, bool Q = false> struct ClG {          // Q: several condition tokens -- the ca_block keeps its query and proj_out stages (G, H)
     static constexpr int S = 256 / C;                  // dims of q / k / v' / y per CU
     static constexpr int NB = 1024 / C;                // hidden units of the sa_block MLP per CU
     static constexpr int TA = S / 32;                  // tiles per wave in stage A (waves 0,1: q; 2,3: k; 4,5: v'; 6,7: y) = units per k-half
     static constexpr int TB = 8 / C;                   // tiles per wave in stage B = units of stage B = units of stage C
-    static constexpr int U_A = 0, U_AS = TA, U_B = 2 * TA, U_C = U_B + TB, U_D = U_C + TB, U_E = U_D + 1, U_F = U_E + 1, NU = U_F + 2;
-    static constexpr int X1_G = 2 * S + 4;             // granules a CU publishes in X1: v'[S] | y[S] | partial scores [4]
-    // granules per sample: boot [16] | X1 [C][X1_G] | X2 [C][256]
-    static constexpr int G_BOOT = 0, G_X1 = 16, G_X2 = G_X1 + C * X1_G, G_TOTAL = G_X2 + C * 256;
+    static constexpr int U_A = 0, U_AS = TA, U_B = 2 * TA, U_C = U_B + TB;
+    static constexpr int U_G = U_C + TB, U_H = U_G + 1;                       // (Q only) ca query: one unit, waves < S / 16; ca proj_out: two units
+    static constexpr int U_D = Q ? U_H + 2 : U_C + TB, U_E = U_D + 1, U_F = U_E + 1, NU_REAL = U_F + 2;
+    static constexpr int NU = (NU_REAL + 3) / 4 * 4;   // padded with phantom units: ring positions repeat per layer
+    static constexpr int SC = Q ? 8 : 4;               // partial-score granules a CU publishes (2 + N values, padded)
+    static constexpr int X1_G = 2 * S + SC;            // granules a CU publishes in X1: v'[S] | y[S] | partial scores [SC]
+    // granules per sample: boot [16] | X1 [C][X1_G] | X2 [C][256] | X3 [C][8] (Q: partial softmax / key products of the ca query)
+    static constexpr int G_BOOT = 0, G_X1 = 16, G_X2 = G_X1 + C * X1_G, G_X3 = G_X2 + C * 256, G_TOTAL = G_X3 + (Q ? C * 8 : 0);
+    static constexpr int EPL = Q ? 3 : 2;              // exchanges (epochs) per layer
 };
 #define DCL_HDR_BYTES 256   // header of the exchange buffer: [0] give-up code, [1] clusters that used L2-local stores
 
@@ -72,13 +77,15 @@ struct ClArgs {
 };
 
 // ---- one unit of the weight stream -> its ring slot
-template <typename WT, int C, int U>
+template <typename WT, int C, bool Q, int U>
 __device__ __forceinline__ void cl_issue(ClRing<WT>& ring, int wave, unsigned voff, __amdgpu_buffer_rsrc_t rsrc,
                                          unsigned base_cur, unsigned base_next, bool skip_cur, bool skip_next) {
-    typedef ClW<WT> W; typedef ClG<C> G;
+    typedef ClW<WT> W; typedef ClG<C, Q> G;
     constexpr int UU = U % G::NU;
     constexpr bool NXT = U >= G::NU;
     static_assert(U < 2 * G::NU && G::NU % W::RU == 0, "ring positions must repeat per layer");
+    if constexpr (UU >= G::NU_REAL) return;            // phantom unit (padding of the layer program)
+    if constexpr (Q && UU == G::U_G) { if (wave >= G::S / 16) return; }       // the ca query has S / 16 tiles: one per wave
     const bool sk = NXT ? skip_next : skip_cur;
     if constexpr (UU < G::U_B) {                       // stage A: the skip half only where the layer has a skip linear; the y waves likewise
         if constexpr (UU >= G::U_AS) { if (!sk) return; }
@@ -161,7 +168,7 @@ __device__ __forceinline__ void cl_zero(f32x4 (&acc)[TPW]) {
 // to cl_refills, after the exchange: loads queued in this CU's vector-memory path right before the publish / poll are latency
 // on the exchange (the hand-off's price sits in the consumer CU's own memory queue, MI355X_MICROARCH.md handoff-1to1).  Units
 // further than RU from the end of such a stage must re-fill inline: their targets are consumed inside the same stage.
-template <typename WT, int C, int U0, int NUN, int TPW, int UI0, int KBOFF, int NINL, int... Is>
+template <typename WT, int C, bool Q, int U0, int NUN, int TPW, int UI0, int KBOFF, int NINL, int... Is>
 __device__ __forceinline__ void cl_units(ClRing<WT>& ring, const ClX& x, f32x4 (&acc)[TPW], bool active, int wave, unsigned voff,
                                          __amdgpu_buffer_rsrc_t rsrc, unsigned bc, unsigned bn, bool sc, bool sn, std::integer_sequence<int, Is...>) {
     typedef ClW<WT> W;
@@ -170,15 +177,15 @@ __device__ __forceinline__ void cl_units(ClRing<WT>& ring, const ClX& x, f32x4 (
         if (active) { cl_consume<WT, TPW, (UI0 + Is) * W::UL, KBOFF>(ring.r[U % W::RU], x, acc); }
         cl_pin<TPW>(acc);
         if constexpr (Is < NINL) {
-            cl_issue<WT, C, U + W::RU>(ring, wave, voff, rsrc, bc, bn, sc, sn);
+            cl_issue<WT, C, Q, U + W::RU>(ring, wave, voff, rsrc, bc, bn, sc, sn);
             cl_pin<TPW>(acc);
         }
     }()), ...);
 }
-template <typename WT, int C, int U0, int... Is>
+template <typename WT, int C, bool Q, int U0, int... Is>
 __device__ __forceinline__ void cl_refills(ClRing<WT>& ring, int wave, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned bc, unsigned bn,
                                            bool sc, bool sn, std::integer_sequence<int, Is...>) {
-    (cl_issue<WT, C, U0 + Is + ClW<WT>::RU>(ring, wave, voff, rsrc, bc, bn, sc, sn), ...);
+    (cl_issue<WT, C, Q, U0 + Is + ClW<WT>::RU>(ring, wave, voff, rsrc, bc, bn, sc, sn), ...);
     __builtin_amdgcn_sched_barrier(0);
 }
 constexpr int cl_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -196,14 +203,13 @@ __device__ __forceinline__ unsigned cl_tags_ok(const u32x4& a, unsigned epoch) {
 // condition token's K | V', the tabulated ca term): 22-23 pieces of at most 1 KiB = 17.9 KB at C = 8, three per wave: one requested at the top
 // of each of the phases B, D and F and stored to LDS at its end, so that the load's latency passes behind the phase.  (As 36 KB of LDS-DMA -- stage_dma, what k_den_sample
 // does -- the same operands cost this kernel 1.9 k cycles per layer: LDS-DMA moves ~40 GB/s per CU, and here nothing overlaps it.)
-template <int C>
+template <int C, bool Q>
 struct ClStage {
-    float4 r; int dst, n4;        // ONE piece per wave and phase (k = 0 in phase B, 1 in D, 2 in F): 4 registers live across a phase
+    float4 r; int dst, n4;        // ONE piece per wave and phase (!Q: k = 0 in phase B, 1 in D, 2 in F; Q: B, C, H, D, F): 4 registers live across a phase
+    static constexpr int NL1 = ClG<C, Q>::NB > 256 ? ClG<C, Q>::NB / 256 : 1;
     __device__ __forceinline__ void load(int k, int wave, int lane, const float* __restrict__ vpg, const DenLayerOff* __restrict__ L,
                                          const float* __restrict__ tt_row, int l, const SeemeSampleArgs& A, int b, int c, int ca_r, int ca_R) {
-        typedef ClG<C> G;
-        constexpr int NL1 = G::NB > 256 ? G::NB / 256 : 1, NSEG = 21 + NL1;
-        static_assert(NSEG <= 24, "three pieces per wave");
+        typedef ClG<C, Q> G;
         const float* vb = vpg + L->skip_b;
         const int o_in = (int)(L->in_b - L->skip_b);
         const int i = wave + 8 * k;
@@ -217,9 +223,25 @@ struct ClStage {
         }
         else if (i <= 15) { src = tt_row + l * 512 + (i - 14) * 256; d = VP_LAYER + (i - 14) * 256; n = 64; }                 // time token K | V'
         else if (i <= 17) { src = tt_row + 2560 + l * 1024 + 512 + (i - 16) * 256; d = VP_LAYER + 1024 + (i - 16) * 256; n = 64; }   // ffn AdaLN scale | shift
-        else if (i <= 19) { src = A.ctab + (size_t)b * SEEME_CROW + l * 512 + (i - 18) * 256; d = VP_LAYER + STG_TT + (i - 18) * 256; n = 64; }
-        else if (i == 20) { src = A.catab + (((size_t)b * ca_R + ca_r) * SEEME_DEN_NL + l) * 256; d = VP_LAYER + STG_TT + 1024; n = 64; }
-        else if (i < NSEG) { d = (int)(L->l1b - L->skip_b) + c * G::NB + (i - 21) * 256; src = vb + d; n = G::NB >= 256 ? 64 : G::NB / 4; }
+        else if (i < 18 + NL1) { d = (int)(L->l1b - L->skip_b) + c * G::NB + (i - 18) * 256; src = vb + d; n = G::NB >= 256 ? 64 : G::NB / 4; }
+        else if constexpr (!Q) {
+            const int j = i - 18 - NL1;
+            if (j <= 1) { src = A.ctab + (size_t)b * SEEME_CROW + l * 512 + j * 256; d = VP_LAYER + STG_TT + j * 256; n = 64; }             // sa K | V' of the condition token
+            else if (j == 2) { src = A.catab + (((size_t)b * ca_R + ca_r) * SEEME_DEN_NL + l) * 256; d = VP_LAYER + STG_TT + 1024; n = 64; }   // its tabulated ca term
+        } else {
+            const int j = i - 18 - NL1;
+            if (j <= 1) { src = tt_row + 2560 + l * 1024 + j * 256; d = VP_LAYER + 512 + j * 256; n = 64; }                                 // ca AdaLN scale | shift
+            else if (j <= 6) {
+                const int64_t f = j == 2 ? L->cnw : j == 3 ? L->cnb : j == 4 ? L->csnw : j == 5 ? L->csnb : L->cao_b;
+                d = (int)(f - L->skip_b); src = vb + d; n = 64;
+            }
+            else if (j == 7) { d = (int)(L->caq_b - L->skip_b) + c * G::S; src = vb + d; n = G::S / 4; }
+            else if (j < 8 + 4 * A.N) {                // condition tokens: sa K | sa V' | ca key | ca value, 256 floats each
+                const int t = (j - 8) >> 2, q = (j - 8) & 3;
+                src = A.ctab + ((size_t)b * A.N + t) * SEEME_CROW + (q < 2 ? l * 512 + q * 256 : 2560 + l * 512 + (q - 2) * 256);
+                d = VP_LAYER + STG_TT + t * 1024 + q * 256; n = 64;
+            }
+        }
         dst = d; n4 = n;
         r = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lane < n) r = *reinterpret_cast<const float4*>(src + 4 * lane);
@@ -228,11 +250,13 @@ struct ClStage {
         if (lane < n4) *reinterpret_cast<float4*>(stg + dst + 4 * lane) = r;
     }
 };
+// pieces: !Q 21 + NL1 <= 24 (three phases x 8 waves); Q 26 + NL1 + 4 N <= 40 (five phases) for N <= 2 (C = 2: N = 2 gives 36)
+#define DCL_MAX_N 2
 
-template <typename WT, int C>
+template <typename WT, int C, bool Q>
 __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    typedef ClW<WT> W; typedef ClG<C> G;
+    typedef ClW<WT> W; typedef ClG<C, Q> G;
     // re-fills left until after the exchange: the last RU units of stage A (x half + skip half) and of stage C
     constexpr int A_DEF0 = cl_clamp(2 * G::TA - W::RU, 0, 2 * G::TA);          // first deferred unit of the 2 TA units of stage A
     constexpr int A_INL0 = cl_clamp(A_DEF0, 0, G::TA), A_INL1 = cl_clamp(A_DEF0 - G::TA, 0, G::TA), C_INL = cl_clamp(G::TB - W::RU, 0, G::TB);
@@ -248,8 +272,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
     else { b = blockIdx.x / C; c = blockIdx.x % C; }
     if (b >= A.B) return;                                      // (whole clusters: every member sees the same b)
     const bool epi = wave == 0;
-    const int N = 1;
-    const int stg_sz = VP_LAYER + STG_TT + N * 1024 + 256;
+    const int N = Q ? A.N : 1;
+    const int stg_sz = VP_LAYER + STG_TT + N * 1024 + (Q ? 0 : 256);
     const int ca_R = A.trow_per_sample ? 1 : A.steps;
 
     float* CONSTV = smem;                        // [768]  query_pos.pe[0], encoder.norm.{weight,bias}
@@ -285,7 +309,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
     float4 xr = ld4(A.latents + (size_t)b * 256 + 4 * lane);
     for (int i = tid; i < 192; i += DEN_THREADS)
         st4(CONSTV + 4 * i, i < 64 ? ld4(vp + lay->pe0 + 4 * i) : (i < 128 ? ld4(vp + lay->fnw + 4 * (i - 64)) : ld4(vp + lay->fnb + 4 * (i - 128))));
-    stage_dma<1, false, 0, 0>(wave, lane, STG, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b, N, 0, ca_R);
+    stage_dma<1, Q, 0, 0>(wave, lane, STG, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b, N, 0, ca_R);
     for (int i = tid; i < XZERO / 4; i += DEN_THREADS) st4(XA + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
     bool dead = false, local = false;
     if (epi) {
@@ -315,9 +339,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
     ClRing<WT> ring;
     {
         const unsigned b0 = (unsigned)((0 * C + c) * G::NU) * W::UNIT_BYTES;
-        cl_issue<WT, C, 0>(ring, wave, voff, wg, b0, b0, false, false);
-        cl_issue<WT, C, 1>(ring, wave, voff, wg, b0, b0, false, false);
-        if constexpr (W::RU == 4) { cl_issue<WT, C, 2>(ring, wave, voff, wg, b0, b0, false, false); cl_issue<WT, C, 3>(ring, wave, voff, wg, b0, b0, false, false); }
+        cl_issue<WT, C, Q, 0>(ring, wave, voff, wg, b0, b0, false, false);
+        cl_issue<WT, C, Q, 1>(ring, wave, voff, wg, b0, b0, false, false);
+        if constexpr (W::RU == 4) { cl_issue<WT, C, Q, 2>(ring, wave, voff, wg, b0, b0, false, false); cl_issue<WT, C, Q, 3>(ring, wave, voff, wg, b0, b0, false, false); }
     }
     __syncthreads();
     int cur = 0;
@@ -347,18 +371,22 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
             const float* v_f1b = VP + (L->f1b - L->skip_b), *v_f2b = VP + (L->f2b - L->skip_b);
             const float* v_fsnw = VP + (L->fsnw - L->skip_b), *v_fsnb = VP + (L->fsnb - L->skip_b);
             const float* v_fo_b = VP + (L->fo_b - L->skip_b);
+            const float* v_cnw = VP + (L->cnw - L->skip_b), *v_cnb = VP + (L->cnb - L->skip_b), *v_caq_b = VP + (L->caq_b - L->skip_b);
+            const float* v_csnw = VP + (L->csnw - L->skip_b), *v_csnb = VP + (L->csnb - L->skip_b), *v_cao_b = VP + (L->cao_b - L->skip_b);
+            (void)v_cnw; (void)v_cnb; (void)v_caq_b; (void)v_csnw; (void)v_csnb; (void)v_cao_b;
             const bool ywave = wave >= 6;
-            const unsigned e1 = 1u + 2u * (unsigned)(step * SEEME_DEN_NL + l), e2 = e1 + 1u;   // epochs of this layer's two exchanges
+            const unsigned e1 = 1u + (unsigned)G::EPL * (unsigned)(step * SEEME_DEN_NL + l), e2 = e1 + 1u, e3 = e1 + 2u;   // epochs of this layer's exchanges
+            (void)e3;
 
             // ================= A: in_proj' (+ folded skip linear), column-split by dims =================
             {
                 f32x4 acc[G::TA];
                 cl_zero<G::TA>(acc);
                 const bool act = skip || !ywave;
-                cl_units<WT, C, G::U_A, G::TA, G::TA, 0, 0, A_INL0>(ring, xa, acc, act, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TA>{});
+                cl_units<WT, C, Q, G::U_A, G::TA, G::TA, 0, 0, A_INL0>(ring, xa, acc, act, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TA>{});
                 {   // second k-half: the skip input (output of layer 1 for layer 3, of layer 0 for layer 4: xs.pop(), cross_attention.py:77-79)
                     const ClX xs = cl_xin<WT>(SKF + (l == 3 ? 512 : 0), lane);
-                    cl_units<WT, C, G::U_AS, G::TA, G::TA, G::TA, W::UL, A_INL1>(ring, xs, acc, skip, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TA>{});
+                    cl_units<WT, C, Q, G::U_AS, G::TA, G::TA, G::TA, W::UL, A_INL1>(ring, xs, acc, skip, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TA>{});
                 }
                 if (act && lane < 16) {
 #pragma unroll
@@ -375,24 +403,36 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
             }
             __syncthreads(); DEN_DBG(0);
             if (epi) {
-                // partial scores over this CU's dims: token 0 itself, the condition token, the time token (last; mdiff_transformer.py:295)
+                // partial scores over this CU's dims: token 0 itself, the condition token(s), the time token (last; mdiff_transformer.py:295)
                 const unsigned epoch = e1;
-                float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+                constexpr int NT = Q ? DCL_MAX_N + 2 : 3;          // score slots: [0] self, [1 .. N] condition, [N + 1] time
+                float ps[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) ps[j] = 0.f;
 #pragma unroll
                 for (int dd = 0; dd < G::S; dd += 64) {
                     const int d = dd + lane;
                     if (d < G::S) {
                         const float q = QS[d];
-                        p0 = fmaf(q, KS[d], p0); p1 = fmaf(q, CT[c * G::S + d], p1); p2 = fmaf(q, TTS[c * G::S + d], p2);
+                        ps[0] = fmaf(q, KS[d], ps[0]);
+#pragma unroll
+                        for (int n = 0; n < NT - 2; ++n) if (n < N) ps[1 + n] = fmaf(q, CT[n * 1024 + c * G::S + d], ps[1 + n]);
+                        ps[NT - 1] = fmaf(q, TTS[c * G::S + d], ps[NT - 1]);
                     }
                 }
-                p0 = wave_sum(p0) * sa_scale; p1 = wave_sum(p1) * sa_scale; p2 = wave_sum(p2) * sa_scale;
-                if (lane < 4) cl_store_granule(xg + G::G_X1 + c * G::X1_G + 2 * G::S + lane, epoch, lane == 0 ? p0 : (lane == 1 ? p1 : (lane == 2 ? p2 : 0.f)), local);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) ps[j] = wave_sum(ps[j]) * sa_scale;
+                {
+                    float pv = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) pv = lane == j ? ps[j] : pv;
+                    if (lane < G::SC) cl_store_granule(xg + G::G_X1 + c * G::X1_G + 2 * G::S + lane, epoch, pv, local);
+                }
                 // ---- X1: gather v' (and y), all-reduce the scores
                 const int pub = (4 * lane) / G::S, off = (4 * lane) % G::S;
                 const unsigned o_v = (unsigned)((G::G_X1 + pub * G::X1_G + off) * 8);
                 const unsigned o_s = (unsigned)((G::G_X1 + (lane % C) * G::X1_G + 2 * G::S) * 8);
-                u32x4 gv0, gv1, gy0, gy1, gs0, gs1;
+                u32x4 gv0, gv1, gy0, gy1, gs[G::SC / 2];
                 gy0 = gy1 = u32x4{0u, epoch, 0u, epoch};
                 unsigned spins = 0;
                 for (;;) {
@@ -402,26 +442,36 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                         gy0 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_v + G::S * 8, 0, 16);
                         gy1 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_v + G::S * 8 + 16, 0, 16);
                     }
-                    gs0 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_s, 0, 16);
-                    gs1 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_s + 16, 0, 16);
-                    const unsigned ok = cl_tags_ok(gv0, epoch) & cl_tags_ok(gv1, epoch) & cl_tags_ok(gy0, epoch) & cl_tags_ok(gy1, epoch)
-                                  & cl_tags_ok(gs0, epoch) & cl_tags_ok(gs1, epoch);
+#pragma unroll
+                    for (int j = 0; j < G::SC / 2; ++j) gs[j] = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_s + 16 * j, 0, 16);
+                    unsigned ok = cl_tags_ok(gv0, epoch) & cl_tags_ok(gv1, epoch) & cl_tags_ok(gy0, epoch) & cl_tags_ok(gy1, epoch);
+#pragma unroll
+                    for (int j = 0; j < G::SC / 2; ++j) ok &= cl_tags_ok(gs[j], epoch);
                     if (__all(ok != 0u) || dead) break;
                     if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 2u); break; }
                 }
                 DEN_DBG(0);
-                float s0 = __uint_as_float(gs0.x), s1 = __uint_as_float(gs0.z), s2 = __uint_as_float(gs1.x);
-                // sum over the C publishers (aligned groups of C lanes hold one each): butterfly, the same order on every CU
-                if (C >= 2) { s0 += dpp_f(s0, 0); s1 += dpp_f(s1, 0); s2 += dpp_f(s2, 0); }
-                if (C >= 4) { s0 += dpp_f(s0, 1); s1 += dpp_f(s1, 1); s2 += dpp_f(s2, 1); }
-                if (C >= 8) { s0 += dpp_f(s0, 2); s1 += dpp_f(s1, 2); s2 += dpp_f(s2, 2); }
-                const float mx = fmaxf(s0, fmaxf(s1, s2));
-                const float e0 = fast_exp(s0 - mx), e1 = fast_exp(s1 - mx), e2 = fast_exp(s2 - mx);
-                const float inv = fast_rcp(e0 + e1 + e2);
+                float sc[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    sc[j] = __uint_as_float((j & 1) ? gs[j >> 1].z : gs[j >> 1].x);
+                    // sum over the C publishers (aligned groups of C lanes hold one each): butterfly, the same order on every CU
+                    if (C >= 2) sc[j] += dpp_f(sc[j], 0);
+                    if (C >= 4) sc[j] += dpp_f(sc[j], 1);
+                    if (C >= 8) sc[j] += dpp_f(sc[j], 2);
+                }
+                float mx = fmaxf(sc[0], sc[NT - 1]);
+#pragma unroll
+                for (int n = 0; n < NT - 2; ++n) if (n < N) mx = fmaxf(mx, sc[1 + n]);
+                float esum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) { sc[j] = (j == 0 || j == NT - 1 || j - 1 < N) ? fast_exp(sc[j] - mx) : 0.f; esum += sc[j]; }
+                const float inv = fast_rcp(esum);
                 const float4 vv = make_float4(__uint_as_float(gv0.x), __uint_as_float(gv0.z), __uint_as_float(gv1.x), __uint_as_float(gv1.z));
-                float4 att = f4_scale(vv, e0 * inv);
-                att = f4_fma(e1 * inv, ld4(CT + 256 + 4 * lane), att);
-                att = f4_fma(e2 * inv, ld4(TTS + 256 + 4 * lane), att);
+                float4 att = f4_scale(vv, sc[0] * inv);
+#pragma unroll
+                for (int n = 0; n < NT - 2; ++n) if (n < N) att = f4_fma(sc[1 + n] * inv, ld4(CT + n * 1024 + 256 + 4 * lane), att);
+                att = f4_fma(sc[NT - 1] * inv, ld4(TTS + 256 + 4 * lane), att);
                 if (skip) xr = make_float4(__uint_as_float(gy0.x), __uint_as_float(gy0.z), __uint_as_float(gy1.x), __uint_as_float(gy1.z));
                 xr = wave_ln(f4_add(xr, att), v_n1w, v_n1b, lane);        // the "values" carry out_proj: residual + norm1
                 put_x<WT, 1>(XB, 0, 0, lane, xr);
@@ -431,15 +481,15 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
             // ================= B: linear1 + ReLU, column-split =================
             // (a piece of the next layer's small operands is requested here and stored to the other half of the staging buffer at the end
             //  of the phase -- BEFORE the deferred re-fills: vmcnt is in order, and the store must not wait for them)
-            ClStage<C> nxt;
+            ClStage<C, Q> nxt;
             const float* const tt_next = A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW;
             const int ca_next = A.trow_per_sample ? 0 : (ln == 0 ? step_next : step);
             nxt.load(0, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
-            cl_refills<WT, C, G::U_A + A_DEF0>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2 * G::TA - A_DEF0>{});   // slots of stage A
+            cl_refills<WT, C, Q, G::U_A + A_DEF0>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2 * G::TA - A_DEF0>{});   // slots of stage A
             {
                 f32x4 acc[G::TB];
                 cl_zero<G::TB>(acc);
-                cl_units<WT, C, G::U_B, G::TB, G::TB, 0, 0, G::TB>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB>{});
+                cl_units<WT, C, Q, G::U_B, G::TB, G::TB, 0, 0, G::TB>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB>{});
                 if (lane < 16) {
 #pragma unroll
                     for (int t = 0; t < G::TB; ++t) {
@@ -452,15 +502,17 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
             __syncthreads(); DEN_DBG(0);
 
             // ================= C: linear2, row-split -> X2 =================
+            if constexpr (Q) nxt.load(1, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
             {
                 f32x4 acc[2];
                 cl_zero<2>(acc);
-                cl_units<WT, C, G::U_C, G::TB, 2, 0, 0, C_INL>(ring, xh, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB>{});
+                cl_units<WT, C, Q, G::U_C, G::TB, 2, 0, 0, C_INL>(ring, xh, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB>{});
                 if (lane < 32) {
                     const float val = (lane & 16) ? cl_out<WT>(acc[1]) : cl_out<WT>(acc[0]);
                     cl_store_granule(xg + G::G_X2 + c * 256 + (2 * wave + (lane >> 4)) * 16 + col, e2, val, local);
                 }
             }
+            if constexpr (Q) nxt.store(lane, STG + (cur ^ 1) * stg_sz);
             if (epi) {
                 const unsigned epoch = e2;
                 float4 sum;
@@ -485,21 +537,133 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                     if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 4u); break; }
                 }
                 DEN_DBG(0);
-                // + bias, residual, norm2; ONE condition token: x + Stylization(v) does not depend on x (seeme_denoiser_ca_tables)
+                // + bias, residual, norm2
                 xr = wave_ln(f4_add(xr, f4_add(sum, ld4(v_l2b + 4 * lane))), v_n2w, v_n2b, lane);
-                xr = f4_add(xr, ld4(CA_ADD + 4 * lane));
-                put_x<WT, 1>(XA, 0, 0, lane, xr);
+                if constexpr (!Q) {
+                    // ONE condition token: x + Stylization(v) does not depend on x (seeme_denoiser_ca_tables)
+                    xr = f4_add(xr, ld4(CA_ADD + 4 * lane));
+                    put_x<WT, 1>(XA, 0, 0, lane, xr);
+                } else {
+                    put_x<WT, 1>(XB, 0, 0, lane, wave_ln(xr, v_cnw, v_cnb, lane));       // ca_block.norm -> input of the query (mdiff_transformer.py:229)
+                }
                 st4(RES + 4 * lane, xr);
             }
             __syncthreads(); DEN_DBG(0);
 
+            if constexpr (Q) {
+                // ================= G: ca_block.query, column-split by dims (waves < S / 16 own one tile each) -> X3 =================
+                cl_refills<WT, C, Q, G::U_C + C_INL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB - C_INL>{});   // slots of stage C
+                {
+                    f32x4 acc[1];
+                    cl_zero<1>(acc);
+                    const bool act = wave < G::S / 16;
+                    cl_units<WT, C, Q, G::U_G, 1, 1, 0, 0, 0>(ring, xb, acc, act, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
+                    if (act && lane < 16) QS[wave * 16 + col] = cl_out<WT>(acc[0]) + v_caq_b[c * G::S + wave * 16 + col];
+                }
+                __syncthreads(); DEN_DBG(0);
+                if (epi) {
+                    // The query softmax runs over all 256 dims (one head), the key softmax over the N tokens per dim (mdiff_transformer.py:231-232).
+                    // This CU holds S dims: local maximum m, e = exp(q - m), l = sum e, and per token t_n = sum_d e_d kc_n[d]; the cluster
+                    // combines them like a split softmax: M = max m_c, w_c = exp(m_c - M), dot_n = sum_c t_cn w_c / sum_c l_c w_c.
+                    const unsigned epoch = e3;
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int dd = 0; dd < G::S; dd += 64) { const int d = dd + lane; if (d < G::S) m = fmaxf(m, QS[d]); }
+                    m = wave_max(m);
+                    float lsum = 0.f, tn[DCL_MAX_N];
+#pragma unroll
+                    for (int n = 0; n < DCL_MAX_N; ++n) tn[n] = 0.f;
+#pragma unroll
+                    for (int dd = 0; dd < G::S; dd += 64) {
+                        const int d = dd + lane;
+                        if (d < G::S) {
+                            const float e = fast_exp(QS[d] - m);
+                            lsum += e;
+                            float kr[DCL_MAX_N], kmx = -INFINITY, ks = 0.f;
+#pragma unroll
+                            for (int n = 0; n < DCL_MAX_N; ++n) if (n < N) { kr[n] = CT[n * 1024 + 512 + c * G::S + d]; kmx = fmaxf(kmx, kr[n]); }
+#pragma unroll
+                            for (int n = 0; n < DCL_MAX_N; ++n) if (n < N) { kr[n] = fast_exp(kr[n] - kmx); ks += kr[n]; }
+                            const float rks = fast_rcp(ks);
+#pragma unroll
+                            for (int n = 0; n < DCL_MAX_N; ++n) if (n < N) tn[n] = fmaf(e, kr[n] * rks, tn[n]);
+                        }
+                    }
+                    lsum = wave_sum(lsum);
+#pragma unroll
+                    for (int n = 0; n < DCL_MAX_N; ++n) tn[n] = wave_sum(tn[n]);
+                    {
+                        float pv = lane == 0 ? m : (lane == 1 ? lsum : 0.f);
+#pragma unroll
+                        for (int n = 0; n < DCL_MAX_N; ++n) pv = lane == 2 + n ? tn[n] : pv;
+                        if (lane < 8) cl_store_granule(xg + G::G_X3 + c * 8 + lane, epoch, pv, local);
+                    }
+                    const unsigned o3 = (unsigned)((G::G_X3 + (lane % C) * 8) * 8);
+                    u32x4 g3[4];
+                    unsigned spins = 0;
+                    for (;;) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) g3[j] = __builtin_amdgcn_raw_buffer_load_b128(xr_, o3 + 16 * j, 0, 16);
+                        unsigned ok = 1u;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ok &= cl_tags_ok(g3[j], epoch);
+                        if (__all(ok != 0u) || dead) break;
+                        if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 8u); break; }
+                    }
+                    DEN_DBG(0);
+                    // lane group of C publishers: [m, l, t_0 .. ] of publisher lane % C
+                    const float mc = __uint_as_float(g3[0].x), lc = __uint_as_float(g3[0].z);
+                    float M = mc;
+                    if (C >= 2) M = fmaxf(M, dpp_f(M, 0));
+                    if (C >= 4) M = fmaxf(M, dpp_f(M, 1));
+                    if (C >= 8) M = fmaxf(M, dpp_f(M, 2));
+                    const float wc = fast_exp(mc - M);
+                    float Lw = lc * wc;
+                    if (C >= 2) Lw += dpp_f(Lw, 0);
+                    if (C >= 4) Lw += dpp_f(Lw, 1);
+                    if (C >= 8) Lw += dpp_f(Lw, 2);
+                    const float rL = fast_rcp(Lw);
+                    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int n = 0; n < DCL_MAX_N; ++n) {
+                        if (n < N) {
+                            float t = __uint_as_float((n & 1) ? g3[1 + (n >> 1)].z : g3[1 + (n >> 1)].x) * wc;
+                            if (C >= 2) t += dpp_f(t, 0);
+                            if (C >= 4) t += dpp_f(t, 1);
+                            if (C >= 8) t += dpp_f(t, 2);
+                            y = f4_fma(t * rL, ld4(CT + n * 1024 + 768 + 4 * lane), y);            // (q k^T) v  (:236-237)
+                        }
+                    }
+                    // StylizationBlock (mdiff_transformer.py:152-163): SiLU(LN(y) (1 + scale) + shift) -> proj_out.out_layers
+                    const float4 hh = f4_adaln(wave_ln(y, v_csnw, v_csnb, lane), ld4(TTS + 512 + 4 * lane), ld4(TTS + 768 + 4 * lane));
+                    put_x<WT, 1>(XB, 0, 0, lane, f4_silu(hh));
+                }
+                __syncthreads(); DEN_DBG(0);
+                // ================= H: ca_block.proj_out.out_layers + residual (replicated) =================
+                cl_refills<WT, C, Q, G::U_G>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});                    // slot of stage G
+                nxt.load(2, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
+                {
+                    f32x4 acc[2];
+                    cl_zero<2>(acc);
+                    cl_units<WT, C, Q, G::U_H, 2, 2, 0, 0, 2>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2>{});
+                    if (lane < 32) {
+                        const int n = (2 * wave + (lane >> 4)) * 16 + col;
+                        const float x3 = RES[n] + ((lane & 16) ? cl_out<WT>(acc[1]) : cl_out<WT>(acc[0])) + v_cao_b[n];
+                        RES[n] = x3;
+                        cl_put1<WT>(XA, n, x3);
+                    }
+                }
+                nxt.store(lane, STG + (cur ^ 1) * stg_sz);
+                __syncthreads(); DEN_DBG(0);
+            }
+
             // ================= D: ffn.linear1 + GELU (replicated) =================
-            nxt.load(1, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
-            cl_refills<WT, C, G::U_C + C_INL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB - C_INL>{});       // slots of stage C
+            nxt.load(Q ? 3 : 1, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
+            if constexpr (!Q) cl_refills<WT, C, Q, G::U_C + C_INL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB - C_INL>{});       // slots of stage C
             {
                 f32x4 acc[1];
                 cl_zero<1>(acc);
-                cl_units<WT, C, G::U_D, 1, 1, 0, 0, 1>(ring, xa, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
+                cl_units<WT, C, Q, G::U_D, 1, 1, 0, 0, 1>(ring, xa, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
                 if (lane < 16) {
                     const int j = wave * 16 + col;
                     cl_put1<WT>(XH, j, fast_gelu(cl_out<WT>(acc[0]) + v_f1b[j]));
@@ -511,7 +675,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
             {
                 f32x4 acc[2];
                 cl_zero<2>(acc);
-                cl_units<WT, C, G::U_E, 1, 2, 0, 0, 1>(ring, xh, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
+                cl_units<WT, C, Q, G::U_E, 1, 2, 0, 0, 1>(ring, xh, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
                 if (lane < 32) PART[(2 * wave + (lane >> 4)) * 16 + col] = (lane & 16) ? cl_out<WT>(acc[1]) : cl_out<WT>(acc[0]);
             }
             __syncthreads(); DEN_DBG(0);
@@ -522,11 +686,11 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
             }
             __syncthreads(); DEN_DBG(0);
             // ================= F: ffn.proj_out.out_layers + residual (replicated); writes the next layer's input =================
-            nxt.load(2, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
+            nxt.load(Q ? 4 : 2, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
             {
                 f32x4 acc[2];
                 cl_zero<2>(acc);
-                cl_units<WT, C, G::U_F, 2, 2, 0, 0, 2>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2>{});
+                cl_units<WT, C, Q, G::U_F, 2, 2, 0, 0, 2>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2>{});
                 if (lane < 32) {
                     const int n = (2 * wave + (lane >> 4)) * 16 + col;
                     const float xn = RES[n] + ((lane & 16) ? cl_out<WT>(acc[1]) : cl_out<WT>(acc[0])) + v_fo_b[n];
@@ -536,6 +700,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                 }
             }
             nxt.store(lane, STG + (cur ^ 1) * stg_sz);
+            // (phantom units that pad the layer program are never consumed: the re-fills they would trigger go out here)
+            cl_refills<WT, C, Q, G::NU_REAL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::NU - G::NU_REAL>{});
             __syncthreads(); DEN_DBG(0);
             if (l + 1 < SEEME_DEN_NL) {
                 if (epi && !nskip) xr = ld4(RES + 4 * lane);                          // residual of the next layer's attention
@@ -581,54 +747,60 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
 }
 
 template <int C>
-static size_t cl_lds_bytes() {
+static size_t cl_lds_bytes(int N, bool q) {
     typedef ClG<C> G;
-    const int stg_sz = VP_LAYER + STG_TT + 1024 + 256;
+    const int stg_sz = VP_LAYER + STG_TT + N * 1024 + (q ? 0 : 256);
     return (size_t)(768 + 256 + 2 * stg_sz + 512 + 512 + 2 * (G::NB > 128 ? G::NB : 128) + 1024 + 2 * G::S + 256 + 256 + 4) * sizeof(float);
 }
 
-extern "C" size_t seeme_den_cluster_xchg_bytes(int B, int C) {
-    const size_t per = C == 8 ? ClG<8>::G_TOTAL : (C == 4 ? ClG<4>::G_TOTAL : ClG<2>::G_TOTAL);
+extern "C" size_t seeme_den_cluster_xchg_bytes(int B, int C) {       // (the several-token layout: the larger of the two)
+    const size_t per = C == 8 ? ClG<8, true>::G_TOTAL : (C == 4 ? ClG<4, true>::G_TOTAL : ClG<2, true>::G_TOTAL);
     const size_t clusters = (size_t)(B + 7) / 8 * 8;
     return DCL_HDR_BYTES + clusters * per * 8;
 }
-// out[0] = units per (layer, CU), [1] = bytes per unit, [2] = image bytes, [3] = wave-loads per unit, [4] = k per wave-load,
-// [5..11] = first unit of A (x half), A (skip half), B, C, D, E, F
-extern "C" int seeme_den_cluster_layout(int C, int wdtype, int64_t* out, int cap) {
-    if (cap < 12) return seeme_fail("den_cluster_layout: output too small");
+// query = 0: one condition token (tabulated ca term); 1: several (the ca_block's query and proj_out stages are units of the image).
+// out[0] = units per (layer, CU) incl. phantom padding, [1] = bytes per unit, [2] = image bytes, [3] = wave-loads per unit, [4] = k per wave-load,
+// [5..11] = first unit of A (x half), A (skip half), B, C, D, E, F, [12] = first unit of G (ca query; -1 without), [13] = of H (ca proj_out)
+extern "C" int seeme_den_cluster_layout(int C, int wdtype, int query, int64_t* out, int cap) {
+    if (cap < 14) return seeme_fail("den_cluster_layout: output too small");
     if (C != 2 && C != 4 && C != 8) return seeme_fail("den_cluster_layout: C must be 2, 4 or 8");
     const int TA = 256 / C / 32, TB = 8 / C;
-    const int64_t NU = 2 * TA + 2 * TB + 4, UL = wdtype == 0 ? 16 : 8, UB = 8 * UL * 1024;
+    const int u_c = 2 * TA + TB, u_g = u_c + TB, u_d = query ? u_g + 3 : u_g;
+    const int64_t NU = (u_d + 4 + 3) / 4 * 4, UL = wdtype == 0 ? 16 : 8, UB = 8 * UL * 1024;
     out[0] = NU; out[1] = UB; out[2] = (int64_t)SEEME_DEN_NL * C * NU * UB; out[3] = UL; out[4] = 256 / UL;
-    out[5] = 0; out[6] = TA; out[7] = 2 * TA; out[8] = 2 * TA + TB; out[9] = 2 * TA + 2 * TB; out[10] = out[9] + 1; out[11] = out[9] + 2;
+    out[5] = 0; out[6] = TA; out[7] = 2 * TA; out[8] = u_c; out[9] = u_d; out[10] = u_d + 1; out[11] = u_d + 2;
+    out[12] = query ? u_g : -1; out[13] = query ? u_g + 1 : -1;
     return 0;
 }
 
-template <typename WT, int C>
+template <typename WT, int C, bool Q>
 static int launch_den_cluster(const ClArgs& ka0, hipStream_t st) {
     ClArgs ka = ka0;
     ka.clusters = (ka.s.B + 7) / 8 * 8;
     const int grid = ka.clusters * C;
     if (grid > 256) return seeme_fail("denoiser_sample_cluster: B x C exceeds one workgroup per CU (256)");
-    const size_t lds = cl_lds_bytes<C>();
+    const size_t lds = cl_lds_bytes<C>(Q ? ka.s.N : 1, Q);
     if (lds > 160 * 1024 || lds <= 80 * 1024) return seeme_fail("denoiser_sample_cluster: LDS footprint must force one workgroup per CU");
-    SEEME_HIP(hipFuncSetAttribute((const void*)k_den_cluster<WT, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_den_cluster<WT, C, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // granules and header are zeroed before EVERY launch (tags of an earlier launch must never match)
     SEEME_HIP(hipMemsetAsync(ka.hdr, 0, seeme_den_cluster_xchg_bytes(ka.s.B, C), st));
-    hipLaunchKernelGGL((k_den_cluster<WT, C>), dim3(grid), dim3(DEN_THREADS), lds, st, ka);
+    hipLaunchKernelGGL((k_den_cluster<WT, C, Q>), dim3(grid), dim3(DEN_THREADS), lds, st, ka);
     return seeme_check_launch("k_den_cluster");
 }
 template <typename WT>
-static int launch_den_cluster_c(const ClArgs& ka, int C, hipStream_t st) {
-    if (C == 8) return launch_den_cluster<WT, 8>(ka, st);
-    if (C == 4) return launch_den_cluster<WT, 4>(ka, st);
-    if (C == 2) return launch_den_cluster<WT, 2>(ka, st);
+static int launch_den_cluster_c(const ClArgs& ka, int C, bool q, hipStream_t st) {
+    if (C == 8) return q ? launch_den_cluster<WT, 8, true>(ka, st) : launch_den_cluster<WT, 8, false>(ka, st);
+    if (C == 4) return q ? launch_den_cluster<WT, 4, true>(ka, st) : launch_den_cluster<WT, 4, false>(ka, st);
+    if (C == 2) return q ? launch_den_cluster<WT, 2, true>(ka, st) : launch_den_cluster<WT, 2, false>(ka, st);
     return seeme_fail("denoiser_sample_cluster: C must be 2, 4 or 8");
 }
 
 extern "C" int seeme_denoiser_sample_cluster(const SeemeDenoiserWeights* w, const SeemeDenCluster* cl, const SeemeSampleArgs* a, void* stream) {
     if (a->B <= 0) return seeme_fail("denoiser_sample_cluster: B must be > 0");
-    if (a->N != 1 || a->catab == nullptr || a->force_query) return seeme_fail("denoiser_sample_cluster: one condition token with its ca table");
+    if (a->N < 1 || a->N > DCL_MAX_N) return seeme_fail("denoiser_sample_cluster: 1 or 2 condition tokens");
+    const bool q = a->N > 1;
+    if (!q && (a->catab == nullptr || a->force_query)) return seeme_fail("denoiser_sample_cluster: one condition token needs its ca table");
+    if (q != (cl->query != 0)) return seeme_fail("denoiser_sample_cluster: the weight image was packed for the other ca_block variant (SeemeDenCluster.query)");
     if (w->nhead != 1 || !w->sa_fold) return seeme_fail("denoiser_sample_cluster: one attention head (folded out_proj)");
     if (a->cfg || a->save != nullptr) return seeme_fail("denoiser_sample_cluster: no CFG pair, no training forward");
     if (w->ff_sa != FF_SA || w->ff != FF_D) return seeme_fail("denoiser_sample_cluster: built for sa ff 1024 / ffn_dim 128");
@@ -636,8 +808,8 @@ extern "C" int seeme_denoiser_sample_cluster(const SeemeDenoiserWeights* w, cons
     if (a->steps < 1) return seeme_fail("denoiser_sample_cluster: steps must be >= 1");
     if (cl->xchg == nullptr || cl->xchg_bytes < seeme_den_cluster_xchg_bytes(a->B, cl->C)) return seeme_fail("denoiser_sample_cluster: exchange buffer too small");
     if (((uintptr_t)cl->xchg & 15) != 0) return seeme_fail("denoiser_sample_cluster: exchange buffer must be 16-byte aligned");
-    int64_t lo[12];
-    int rc = seeme_den_cluster_layout(cl->C, cl->wdtype, lo, 12);
+    int64_t lo[14];
+    int rc = seeme_den_cluster_layout(cl->C, cl->wdtype, q ? 1 : 0, lo, 14);
     if (rc) return rc;
     ClArgs ka;
     ka.wgc = cl->wgc; ka.wgc_bytes = (unsigned)lo[2]; ka.vp = cl->vpc;
@@ -647,8 +819,8 @@ extern "C" int seeme_denoiser_sample_cluster(const SeemeDenoiserWeights* w, cons
     ka.xg = (unsigned long long*)((char*)cl->xchg + DCL_HDR_BYTES);
     ka.placement = cl->placement; ka.flags = cl->flags; ka.clusters = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (cl->wdtype == 0) return launch_den_cluster_c<WF32>(ka, cl->C, st);
-    if (cl->wdtype == 1) return launch_den_cluster_c<WBF16>(ka, cl->C, st);
-    if (cl->wdtype == 2) return launch_den_cluster_c<WF16>(ka, cl->C, st);
+    if (cl->wdtype == 0) return launch_den_cluster_c<WF32>(ka, cl->C, q, st);
+    if (cl->wdtype == 1) return launch_den_cluster_c<WBF16>(ka, cl->C, q, st);
+    if (cl->wdtype == 2) return launch_den_cluster_c<WF16>(ka, cl->C, q, st);
     return seeme_fail("denoiser_sample_cluster: wdtype must be 0 (fp32), 1 (bf16) or 2 (fp16)");
 }

@@ -158,7 +158,7 @@ class MldDenoiser(nn.Module):
         if weight_dtype not in ("fp32", "bf16", "fp16"):
             raise ValueError("weight_dtype must be 'fp32', 'bf16' or 'fp16'")
         self.weight_dtype = weight_dtype
-        # CUs per sample in sample_loop / forward: "auto" (8 / 4 / 2 while B x C <= 256, i.e. batches that leave most of the chip
+        # CUs per sample in sample_loop / forward: "auto" (8 / 4 / 2 while B x C <= 256 -- one head, at most two condition tokens, no CFG pair --, i.e. batches that leave most of the chip
         # idle; one CU per sample beyond), 0 (never) or 2 / 4 / 8.  SEEME_DEN_CLUSTER overrides.  Speed only.
         if cluster not in ("auto", 0, 2, 4, 8):
             raise ValueError("cluster must be 'auto', 0, 2, 4 or 8")
@@ -302,21 +302,23 @@ class MldDenoiser(nn.Module):
         return w
 
     # ------------------------------------------------------------------ cluster image (csrc/den_cluster.inc.hip)
-    def _cluster_weights(self, Cc: int):
+    def _cluster_weights(self, Cc: int, query: bool = False):
         """Weight image for one sample split over Cc CUs: [layer][CU][unit][wave 8][load][lane 64][16 B] in order of use.
         Stage A = rows c S .. of q | k | W_o v (| y) of [W_in' W_s ; W_s] (layers 3, 4: the skip linear folded in, acting on
         cat[x, skip]; cross_attention.py:77-79) or of W_in' (layers 0-2); B = linear1 rows of the CU's hidden units; C = the
-        matching columns of linear2; D, E, F = ffn.linear1 / linear2 / proj_out whole (replicated)."""
+        matching columns of linear2; D, E, F = ffn.linear1 / linear2 / proj_out whole (replicated).  `query` (several condition tokens):
+        between C and D, G = the rows of ca_block.query of the CU's dims and H = ca_block.proj_out.out_layers whole."""
         self._weights()
-        if Cc in self._ccache:
-            return self._ccache[Cc]
+        if (Cc, query) in self._ccache:
+            return self._ccache[(Cc, query)]
         in_proj, vp, layers = self._fold_parts
         dev = vp.device
         code = {"fp32": 0, "bf16": 1, "fp16": 2}[self.weight_dtype]
         wdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[self.weight_dtype]
-        lo = (C.c_int64 * 12)()
-        L.check(L.lib().seeme_den_cluster_layout(Cc, code, lo, 12), "seeme_den_cluster_layout")
+        lo = (C.c_int64 * 14)()
+        L.check(L.lib().seeme_den_cluster_layout(Cc, code, int(query), lo, 14), "seeme_den_cluster_layout")
         NU, UB, total, UL, KL = (int(v) for v in lo[:5])
+        U_D, U_G, U_H = int(lo[9]), int(lo[12]), int(lo[13])
         EPL = KL // 4                                   # elements per lane per wave-load (16 B)
         S, NB, TA, TB = 256 // Cc, 1024 // Cc, 256 // Cc // 32, 8 // Cc
 
@@ -345,19 +347,25 @@ class MldDenoiser(nn.Module):
                     img[l, c, 0:ua.shape[0]] = ua
                     img[l, c, 2 * TA:2 * TA + TB] = pack_stage(W1[c * NB:(c + 1) * NB].to(wdt), TB)
                     img[l, c, 2 * TA + TB:2 * TA + 2 * TB] = pack_stage(W2[:, c * NB:(c + 1) * NB].to(wdt), 2)
-                    u0 = 2 * TA + 2 * TB
+                    if query:
+                        Wq_ca = blk.ca_block.query.weight.detach()[c * S:(c + 1) * S]          # S / 16 tiles, one per wave; the other waves idle
+                        Wq_pad = torch.zeros(128, 256, dtype=Wq_ca.dtype, device=dev)
+                        Wq_pad[:S] = Wq_ca
+                        img[l, c, U_G:U_G + 1] = pack_stage(Wq_pad.to(wdt), 1)
+                        img[l, c, U_H:U_H + 2] = pack_stage(blk.ca_block.proj_out.out_layers[2].weight.detach().to(wdt), 2)
+                    u0 = U_D
                     img[l, c, u0:u0 + 1] = pack_stage(Wf1.to(wdt), 1)
                     img[l, c, u0 + 1:u0 + 2] = pack_stage(Wf2.to(wdt), 2)
                     img[l, c, u0 + 2:u0 + 4] = pack_stage(Wfo.to(wdt), 2)
         assert img.numel() * img.element_size() == total
-        self._ccache[Cc] = (img, vpc, code)
-        return self._ccache[Cc]
+        self._ccache[(Cc, query)] = (img, vpc, code)
+        return self._ccache[(Cc, query)]
 
     def _cluster_size(self, B: int, N: int, cfg: bool) -> int:
         """CUs per sample for this launch (0: the one-CU-per-sample kernel)."""
         want = os.environ.get("SEEME_DEN_CLUSTER")
         want = self.cluster if want is None else (want if want == "auto" else int(want))
-        if want == 0 or N != 1 or cfg or self.num_heads != 1:
+        if want == 0 or N > 2 or cfg or self.num_heads != 1:
             return 0
         Bp = (B + 7) // 8 * 8
         if want == "auto":
@@ -431,7 +439,7 @@ class MldDenoiser(nn.Module):
         w = self._weights()
         Cc = self._cluster_size(B, N, bool(cfg))
         if Cc:
-            img, vpc, code = self._cluster_weights(Cc)
+            img, vpc, code = self._cluster_weights(Cc, N > 1)
             need = L.lib().seeme_den_cluster_xchg_bytes(B, Cc)
             if self._xchg is None or self._xchg.numel() < need or self._xchg.device != latents2d.device:
                 self._xchg = torch.zeros(need, dtype=torch.uint8, device=latents2d.device)
@@ -440,6 +448,7 @@ class MldDenoiser(nn.Module):
             cl.placement = int(os.environ.get("SEEME_DEN_CLUSTER_PLACE", self.cluster_placement))
             cl.flags = int(os.environ.get("SEEME_DEN_CLUSTER_FLAGS", self.cluster_flags))
             cl.xchg, cl.xchg_bytes = self._xchg.data_ptr(), self._xchg.numel()
+            cl.query = int(N > 1)
             L.check(L.lib().seeme_denoiser_sample_cluster(C.byref(w), C.byref(cl), C.byref(a), L.current_stream()),
                     "seeme_denoiser_sample_cluster")
             return out

@@ -1008,7 +1008,37 @@ def test_cluster_sampler_under_uneven_load(dev):
 
 def test_auto_cluster_policy(dev):
     """cluster='auto': 8 / 4 / 2 CUs per sample while B x C fits one workgroup per CU, the one-CU kernel beyond, for CFG pairs,
-    several condition tokens and several heads."""
+    more than two condition tokens and several heads."""
     den = make_den(dev)
     assert [den._cluster_size(B, 1, False) for B in (1, 32, 33, 64, 65, 128, 129, 256)] == [8, 8, 4, 4, 2, 2, 0, 0]
-    assert den._cluster_size(32, 2, False) == 0 and den._cluster_size(32, 1, True) == 0
+    assert den._cluster_size(32, 2, False) == 8 and den._cluster_size(32, 3, False) == 0 and den._cluster_size(32, 1, True) == 0
+
+
+@pytest.mark.parametrize("Cc", [8, 4, 2])
+def test_cluster_sampler_two_condition_tokens(dev, Cc):
+    """k_den_cluster with scene + interactee (N = 2: the reference's shipped config_mld_egobody.yaml:114): the ca_block keeps its query
+    and proj_out stages (mdiff_transformer.py:219-239, 152-163) -- query column-split by dims, the softmax over head_dim and the per-token
+    products combined across the cluster like a split softmax (third exchange per layer), proj_out replicated.  fp32 weights against the
+    fixture generated from the reference module (denoiser_N2.npz); every weight dtype against the one-CU kernel, both placements, twice
+    bit-identically."""
+    g = load_golden("denoiser_N2.npz")
+    s, c = torch.from_numpy(g["sample"]).to(dev), torch.from_numpy(g["cond"]).to(dev)
+    sch = _sched()
+    sch.set_timesteps(50)
+    torch.manual_seed(3)
+    lat, cond = torch.randn(32, 1, 256, device=dev), torch.randn(32, 2, 256, device=dev)
+    for wd, tol in (("fp32", 1e-5), ("fp16", 8e-4), ("bf16", 8e-3)):
+        den = make_den(dev, cond=("text", "scene", "interactee"), weight_dtype=wd)
+        base = _with_cluster(den, 0).sample_loop(lat, cond, sch)
+        _with_cluster(den, Cc)
+        if wd == "fp32":
+            for t in (981, 501, 1):
+                y = den(sample=s, timestep=torch.tensor(t), encoder_hidden_states=c)[0]
+                assert rel_err(y.cpu().numpy(), g[f"out_t{t}"]) < TOL_F32 and elem_err(y.cpu().numpy(), g[f"out_t{t}"]) < TOL_F32
+            y = den(sample=s, timestep=torch.from_numpy(g["tvec"]).to(dev), encoder_hidden_states=c)[0]
+            assert rel_err(y.cpu().numpy(), g["out_tvec"]) < TOL_F32
+        for place in (0, 1):
+            _with_cluster(den, Cc, place)
+            z, z2 = den.sample_loop(lat, cond, sch), den.sample_loop(lat, cond, sch)
+            assert den.cluster_status()[0] == 0 and torch.equal(z, z2)
+            assert rel_err(z.cpu().numpy(), base.cpu().numpy()) < tol, (wd, place)
