@@ -190,6 +190,47 @@ __device__ __forceinline__ void cl_refills(ClRing<WT>& ring, int wave, unsigned 
 }
 constexpr int cl_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// ---- the windowed load schedule (16-bit images, C = 8, one condition token).  Issuing a 1-KiB wave-load costs the CU's address path 16 cycles
+// and the issuing wave waits its turn, so re-fills requested inline are exposed time: at a phase start every wave stands in the queue (phase B:
+// 2.4 k of its 4 k cycles), before a publish the stores stand behind them.  But while the epilogue wave is in an exchange or in its serial
+// vector algebra the other seven waves have nothing to do.  So they request ONE unit in each such window (56 KiB = 900 cycles of the path):
+//   W?A  right after the epilogue wave has PUBLISHED (its stores go first), while it sleeps DCL_POLL_SLEEP x 64 cycles before its first poll:
+//        the peers' granules are not due earlier than that, and the poll then finds the queue drained instead of standing behind the unit;
+//   W?B  after its sweep, during the vector algebra;   W3  during the ffn epilogue
+// -- released through words in LDS, accessed through the LDS address space (through a generic pointer the compiler emits flat loads waited for
+// with vmcnt(0): seven waves spinning on those sit in the very queue the polls need).  The epilogue wave requests its eighth of a window's
+// unit BEFORE it releases the others (behind them it would wait out their backlog).  The rest (next layer's A1, B, C) goes out in phase F.
+//   units A0 A1 | B | C | D | E | F0 F1 = 0..7:  W1A D | W1B E | W2A F0 | W2B F1 | W3 next A0 | phase F: next A1 | inline in F: next B, C
+#ifndef DCL_POLL_SLEEP
+#define DCL_POLL_SLEEP 12
+#endif
+template <int... Us> using ClSeq = std::integer_sequence<int, Us...>;
+template <int C, bool MF, bool Q> struct ClSched { static constexpr bool WIN = false; static constexpr int PRO = 0; typedef ClSeq<> W1A, W1B, W2A, W2B, W3, PF, AF; };
+#ifndef DCL_SCHED
+#define DCL_SCHED 9
+#endif
+#if DCL_SCHED == 8      // "early": every unit one window ahead of the inline scheme; the next layer's B and C still go out inline in phase F (PRO: units in flight at a layer's start)
+template <> struct ClSched<8, true, false> { static constexpr bool WIN = true; static constexpr int PRO = 4; typedef ClSeq<4> W1A; typedef ClSeq<5> W1B; typedef ClSeq<6> W2A; typedef ClSeq<7> W2B;
+                                             typedef ClSeq<8> W3; typedef ClSeq<9> PF; typedef ClSeq<10, 11> AF; };
+#elif DCL_SCHED == 9    // "just in time": a unit goes out in the window before the phase that consumes it; only the next layer's A is requested inline (after F)
+template <> struct ClSched<8, true, false> { static constexpr bool WIN = true; static constexpr int PRO = 2; typedef ClSeq<2, 3> W1A; typedef ClSeq<4> W1B; typedef ClSeq<5> W2A; typedef ClSeq<6> W2B;
+                                             typedef ClSeq<7> W3; typedef ClSeq<> PF; typedef ClSeq<8, 9> AF; };
+#elif DCL_SCHED == 10   // as 9, with the second exchange window taking two units as well, so that only the skip layers' A1 is left inline
+template <> struct ClSched<8, true, false> { static constexpr bool WIN = true; static constexpr int PRO = 2; typedef ClSeq<2, 3> W1A; typedef ClSeq<4> W1B; typedef ClSeq<5, 6> W2A; typedef ClSeq<7> W2B;
+                                             typedef ClSeq<8> W3; typedef ClSeq<> PF; typedef ClSeq<9> AF; };
+#endif
+template <typename WT, int C, bool Q, int... Us>
+__device__ __forceinline__ void cl_issue_seq(ClRing<WT>& ring, int wave, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned bc, unsigned bn,
+                                             bool sc, bool sn, ClSeq<Us...>) {
+    (cl_issue<WT, C, Q, Us>(ring, wave, voff, rsrc, bc, bn, sc, sn), ...);
+    __builtin_amdgcn_sched_barrier(0);
+}
+typedef __attribute__((address_space(3))) volatile int cl_lds_flag;
+__device__ __forceinline__ void cl_flag_set(int* f, unsigned v) { *(cl_lds_flag*)f = (int)v; }
+__device__ __forceinline__ void cl_flag_wait(const int* f, unsigned v) {      // (set by this workgroup's epilogue wave: always arrives)
+    while (*(const cl_lds_flag*)f != (int)v) __builtin_amdgcn_s_sleep(1);
+}
+
 // ---- granules
 __device__ __forceinline__ void cl_store_granule(unsigned long long* g, unsigned epoch, float v, bool local) {
     const unsigned long long x = ((unsigned long long)epoch << 32) | __float_as_uint(v);
@@ -260,6 +301,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
     // re-fills left until after the exchange: the last RU units of stage A (x half + skip half) and of stage C
     constexpr int A_DEF0 = cl_clamp(2 * G::TA - W::RU, 0, 2 * G::TA);          // first deferred unit of the 2 TA units of stage A
     constexpr int A_INL0 = cl_clamp(A_DEF0, 0, G::TA), A_INL1 = cl_clamp(A_DEF0 - G::TA, 0, G::TA), C_INL = cl_clamp(G::TB - W::RU, 0, G::TB);
+    typedef ClSched<C, WT::MFMA, Q> SCH;
+    constexpr bool WIN = SCH::WIN;       // (then stages A .. E request nothing inline: the windows do)
     const SeemeSampleArgs& A = ka.s;
     const DenLayout* __restrict__ lay = &ka.lay;
     const float* __restrict__ vp = ka.vp;
@@ -311,6 +354,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
         st4(CONSTV + 4 * i, i < 64 ? ld4(vp + lay->pe0 + 4 * i) : (i < 128 ? ld4(vp + lay->fnw + 4 * (i - 64)) : ld4(vp + lay->fnb + 4 * (i - 128))));
     stage_dma<1, Q, 0, 0>(wave, lane, STG, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b, N, 0, ca_R);
     for (int i = tid; i < XZERO / 4; i += DEN_THREADS) st4(XA + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+    if (tid >= 1 && tid < 4) FLG[tid] = 0;                   // window flags (epochs are never 0)
     bool dead = false, local = false;
     if (epi) {
         // first exchange, always write-through: the XCC id of every workgroup of the cluster (HW_REG_XCC_ID, bits 3:0)
@@ -341,7 +385,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
         const unsigned b0 = (unsigned)((0 * C + c) * G::NU) * W::UNIT_BYTES;
         cl_issue<WT, C, Q, 0>(ring, wave, voff, wg, b0, b0, false, false);
         cl_issue<WT, C, Q, 1>(ring, wave, voff, wg, b0, b0, false, false);
-        if constexpr (W::RU == 4) { cl_issue<WT, C, Q, 2>(ring, wave, voff, wg, b0, b0, false, false); cl_issue<WT, C, Q, 3>(ring, wave, voff, wg, b0, b0, false, false); }
+        if constexpr (W::RU == 4 && (!WIN || SCH::PRO == 4)) { cl_issue<WT, C, Q, 2>(ring, wave, voff, wg, b0, b0, false, false); cl_issue<WT, C, Q, 3>(ring, wave, voff, wg, b0, b0, false, false); }
     }
     __syncthreads();
     int cur = 0;
@@ -428,6 +472,12 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                     for (int j = 0; j < NT; ++j) pv = lane == j ? ps[j] : pv;
                     if (lane < G::SC) cl_store_granule(xg + G::G_X1 + c * G::X1_G + 2 * G::S + lane, epoch, pv, local);
                 }
+                if constexpr (WIN) {        // published: this wave's share of W1A, then the others'; the first poll waits until the unit has drained
+                    __builtin_amdgcn_sched_barrier(0);
+                    cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1A{});
+                    if (lane == 0) cl_flag_set(FLG + 1, e1);
+                    __builtin_amdgcn_s_sleep(DCL_POLL_SLEEP);
+                }
                 // ---- X1: gather v' (and y), all-reduce the scores
                 const int pub = (4 * lane) / G::S, off = (4 * lane) % G::S;
                 const unsigned o_v = (unsigned)((G::G_X1 + pub * G::X1_G + off) * 8);
@@ -449,6 +499,10 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                     for (int j = 0; j < G::SC / 2; ++j) ok &= cl_tags_ok(gs[j], epoch);
                     if (__all(ok != 0u) || dead) break;
                     if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 2u); break; }
+                }
+                if constexpr (WIN) {
+                    cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1B{});
+                    if (lane == 0) cl_flag_set(FLG + 2, e1);
                 }
                 DEN_DBG(0);
                 float sc[NT];
@@ -475,6 +529,11 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                 if (skip) xr = make_float4(__uint_as_float(gy0.x), __uint_as_float(gy0.z), __uint_as_float(gy1.x), __uint_as_float(gy1.z));
                 xr = wave_ln(f4_add(xr, att), v_n1w, v_n1b, lane);        // the "values" carry out_proj: residual + norm1
                 put_x<WT, 1>(XB, 0, 0, lane, xr);
+            } else if constexpr (WIN) {
+                cl_flag_wait(FLG + 1, e1);
+                cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1A{});
+                cl_flag_wait(FLG + 2, e1);
+                cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1B{});
             }
             __syncthreads(); DEN_DBG(0);
 
@@ -485,11 +544,11 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
             const float* const tt_next = A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW;
             const int ca_next = A.trow_per_sample ? 0 : (ln == 0 ? step_next : step);
             nxt.load(0, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
-            cl_refills<WT, C, Q, G::U_A + A_DEF0>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2 * G::TA - A_DEF0>{});   // slots of stage A
+            if constexpr (!WIN) cl_refills<WT, C, Q, G::U_A + A_DEF0>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2 * G::TA - A_DEF0>{});   // slots of stage A
             {
                 f32x4 acc[G::TB];
                 cl_zero<G::TB>(acc);
-                cl_units<WT, C, Q, G::U_B, G::TB, G::TB, 0, 0, G::TB>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB>{});
+                cl_units<WT, C, Q, G::U_B, G::TB, G::TB, 0, 0, (WIN ? 0 : G::TB)>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB>{});
                 if (lane < 16) {
 #pragma unroll
                     for (int t = 0; t < G::TB; ++t) {
@@ -515,6 +574,12 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
             if constexpr (Q) nxt.store(lane, STG + (cur ^ 1) * stg_sz);
             if (epi) {
                 const unsigned epoch = e2;
+                if constexpr (WIN) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2A{});
+                    if (lane == 0) cl_flag_set(FLG + 1, e2);
+                    __builtin_amdgcn_s_sleep(DCL_POLL_SLEEP);
+                }
                 float4 sum;
                 unsigned spins = 0;
                 for (;;) {
@@ -536,6 +601,10 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                     if (__all(ok != 0u) || dead) break;
                     if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 4u); break; }
                 }
+                if constexpr (WIN) {
+                    cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2B{});
+                    if (lane == 0) cl_flag_set(FLG + 2, e2);
+                }
                 DEN_DBG(0);
                 // + bias, residual, norm2
                 xr = wave_ln(f4_add(xr, f4_add(sum, ld4(v_l2b + 4 * lane))), v_n2w, v_n2b, lane);
@@ -547,6 +616,11 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                     put_x<WT, 1>(XB, 0, 0, lane, wave_ln(xr, v_cnw, v_cnb, lane));       // ca_block.norm -> input of the query (mdiff_transformer.py:229)
                 }
                 st4(RES + 4 * lane, xr);
+            } else if constexpr (WIN) {
+                cl_flag_wait(FLG + 1, e2);
+                cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2A{});
+                cl_flag_wait(FLG + 2, e2);
+                cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2B{});
             }
             __syncthreads(); DEN_DBG(0);
 
@@ -659,11 +733,11 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
 
             // ================= D: ffn.linear1 + GELU (replicated) =================
             nxt.load(Q ? 3 : 1, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
-            if constexpr (!Q) cl_refills<WT, C, Q, G::U_C + C_INL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB - C_INL>{});       // slots of stage C
+            if constexpr (!Q && !WIN) cl_refills<WT, C, Q, G::U_C + C_INL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB - C_INL>{});       // slots of stage C
             {
                 f32x4 acc[1];
                 cl_zero<1>(acc);
-                cl_units<WT, C, Q, G::U_D, 1, 1, 0, 0, 1>(ring, xa, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
+                cl_units<WT, C, Q, G::U_D, 1, 1, 0, 0, (WIN ? 0 : 1)>(ring, xa, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
                 if (lane < 16) {
                     const int j = wave * 16 + col;
                     cl_put1<WT>(XH, j, fast_gelu(cl_out<WT>(acc[0]) + v_f1b[j]));
@@ -675,22 +749,31 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
             {
                 f32x4 acc[2];
                 cl_zero<2>(acc);
-                cl_units<WT, C, Q, G::U_E, 1, 2, 0, 0, 1>(ring, xh, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
+                cl_units<WT, C, Q, G::U_E, 1, 2, 0, 0, (WIN ? 0 : 1)>(ring, xh, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
                 if (lane < 32) PART[(2 * wave + (lane >> 4)) * 16 + col] = (lane & 16) ? cl_out<WT>(acc[1]) : cl_out<WT>(acc[0]);
             }
             __syncthreads(); DEN_DBG(0);
             if (epi) {
+                if constexpr (WIN) {
+                    cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W3{});
+                    if (lane == 0) cl_flag_set(FLG + 3, e2);
+                }
                 const float4 y2 = f4_add(ld4(PART + 4 * lane), ld4(v_f2b + 4 * lane));
                 const float4 hh = f4_adaln(wave_ln(y2, v_fsnw, v_fsnb, lane), ld4(TTS + 1024 + 4 * lane), ld4(TTS + 1280 + 4 * lane));
                 put_x<WT, 1>(XB, 0, 0, lane, f4_silu(hh));
+            } else if constexpr (WIN) {
+                cl_flag_wait(FLG + 3, e2);
+                cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W3{});
             }
             __syncthreads(); DEN_DBG(0);
             // ================= F: ffn.proj_out.out_layers + residual (replicated); writes the next layer's input =================
             nxt.load(Q ? 4 : 2, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
+            if constexpr (WIN) cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::PF{});
             {
                 f32x4 acc[2];
                 cl_zero<2>(acc);
-                cl_units<WT, C, Q, G::U_F, 2, 2, 0, 0, 2>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2>{});
+                cl_units<WT, C, Q, G::U_F, 2, 2, 0, 0, (WIN ? 0 : 2)>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2>{});
+                if constexpr (WIN) cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::AF{});
                 if (lane < 32) {
                     const int n = (2 * wave + (lane >> 4)) * 16 + col;
                     const float xn = RES[n] + ((lane & 16) ? cl_out<WT>(acc[1]) : cl_out<WT>(acc[0])) + v_fo_b[n];
