@@ -532,7 +532,8 @@ def main():
         loop_ms = e0.elapsed_time(e1)
     alg_bytes = den_algorithmic_bytes(den, B, 1, n_infer)
     achieved = alg_bytes / (loop_ms * 1e-3) / 1e9
-    Cc = den._cluster_size(B, 1, False)
+    from seeme_amd.mld_denoiser import _device_cus
+    Cc = den._cluster_size(B, 1, False, _device_cus(dev))
     if Cc:          # one sample split over Cc CUs: a CU streams its slices + the replicated FFN matrices
         exe_cu = den_cluster_bytes_per_cu(den, Cc, n_infer)
         cus = (B + 7) // 8 * 8 * Cc

@@ -861,7 +861,12 @@ static int launch_den_cluster(const ClArgs& ka0, hipStream_t st) {
     ClArgs ka = ka0;
     ka.clusters = (ka.s.B + 7) / 8 * 8;
     const int grid = ka.clusters * C;
-    if (grid > 256) return seeme_fail("denoiser_sample_cluster: B x C exceeds one workgroup per CU (256)");
+    // co-residency of every workgroup is what the in-launch exchanges rest on: one workgroup per CU of THIS device (a partitioned or
+    // CU-masked device has fewer than 256)
+    int dev = 0, cus = 0;
+    SEEME_HIP(hipGetDevice(&dev));
+    SEEME_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (grid > cus || grid > 256) return seeme_fail("denoiser_sample_cluster: B x C exceeds one workgroup per CU of this device");
     const size_t lds = cl_lds_bytes<C>(Q ? ka.s.N : 1, Q);
     if (lds > 160 * 1024 || lds <= 80 * 1024) return seeme_fail("denoiser_sample_cluster: LDS footprint must force one workgroup per CU");
     SEEME_HIP(hipFuncSetAttribute((const void*)k_den_cluster<WT, C, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -26,6 +26,18 @@ _LAYER_FIELDS = ["skip", "inp", "outp", "l1", "l2", "caq", "cao", "f1", "f2", "f
                  "csnw", "csnb", "cao_b", "f1b", "f2b", "fsnw", "fsnb", "fo_b"]
 
 
+_CUS = {}
+
+
+def _device_cus(device) -> int:
+    """Compute units of `device` (cached): a cluster launch needs all its workgroups resident at once."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _CUS:
+        _CUS[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+    return _CUS[idx]
+
+
 def timestep_features(timesteps: torch.Tensor, dim: int = 256, flip_sin_to_cos: bool = True,
                       freq_shift: float = 0.0, max_period: int = 10000) -> torch.Tensor:
     """Sinusoidal timestep features, tools/embeddings.py:245-285 (host-side plumbing: a [rows,256]
@@ -361,19 +373,21 @@ class MldDenoiser(nn.Module):
         self._ccache[(Cc, query)] = (img, vpc, code)
         return self._ccache[(Cc, query)]
 
-    def _cluster_size(self, B: int, N: int, cfg: bool) -> int:
-        """CUs per sample for this launch (0: the one-CU-per-sample kernel)."""
+    def _cluster_size(self, B: int, N: int, cfg: bool, cus: int = 256) -> int:
+        """CUs per sample for this launch (0: the one-CU-per-sample kernel).  `cus`: compute units of the device -- every
+        workgroup of a cluster launch must be resident at once (one per CU)."""
         want = os.environ.get("SEEME_DEN_CLUSTER")
         want = self.cluster if want is None else (want if want == "auto" else int(want))
         if want == 0 or N > 2 or cfg or self.num_heads != 1:
             return 0
         Bp = (B + 7) // 8 * 8
+        cus = min(int(cus), 256)
         if want == "auto":
             for Cc in (8, 4, 2):
-                if Bp * Cc <= 256:
+                if Bp * Cc <= cus:
                     return Cc
             return 0
-        return want if Bp * want <= 256 else 0
+        return want if Bp * want <= cus else 0
 
     def cluster_status(self):
         """(give-up code, clusters that ran with L2-local granule stores) of the last cluster launch; synchronises."""
@@ -437,7 +451,7 @@ class MldDenoiser(nn.Module):
         a.catab = L.ptr(catab)
         a.xcds = L.default_xcds((B + 1) // 2 if (B > 256 and not per_sample and not cfg) else B, self.pack_xcds)
         w = self._weights()
-        Cc = self._cluster_size(B, N, bool(cfg))
+        Cc = self._cluster_size(B, N, bool(cfg), _device_cus(latents2d.device))
         if Cc:
             img, vpc, code = self._cluster_weights(Cc, N > 1)
             need = L.lib().seeme_den_cluster_xchg_bytes(B, Cc)

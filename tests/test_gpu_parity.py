@@ -1012,6 +1012,8 @@ def test_auto_cluster_policy(dev):
     den = make_den(dev)
     assert [den._cluster_size(B, 1, False) for B in (1, 32, 33, 64, 65, 128, 129, 256)] == [8, 8, 4, 4, 2, 2, 0, 0]
     assert den._cluster_size(32, 2, False) == 8 and den._cluster_size(32, 3, False) == 0 and den._cluster_size(32, 1, True) == 0
+    # a device with fewer CUs (partitioned / masked): every workgroup of a cluster launch must still be resident at once
+    assert [den._cluster_size(32, 1, False, cus=c) for c in (256, 128, 64, 32)] == [8, 4, 2, 0]
 
 
 @pytest.mark.parametrize("Cc", [8, 4, 2])
