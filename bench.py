@@ -533,12 +533,13 @@ def main():
     alg_bytes = den_algorithmic_bytes(den, B, 1, n_infer)
     achieved = alg_bytes / (loop_ms * 1e-3) / 1e9
     from seeme_amd.mld_denoiser import _device_cus
-    Cc = den._cluster_size(B, 1, False, _device_cus(dev))
-    if Cc:          # one sample split over Cc CUs: a CU streams its slices + the replicated FFN matrices
+    Cc, spc = den._cluster_plan(B, 1, False, False, _device_cus(dev))
+    if Cc:          # one sample (or, above B = 64, up to 8) split over Cc CUs: a CU streams its slices + the replicated FFN matrices
         exe_cu = den_cluster_bytes_per_cu(den, Cc, n_infer)
-        cus = (B + 7) // 8 * 8 * Cc
+        cus = ((B + spc - 1) // spc + 7) // 8 * 8 * Cc
         exe_bytes = exe_cu * cus
-        kname = f"k_den_cluster (persistent DDIM loop, one sample split over {Cc} CUs)"
+        kname = (f"k_den_cluster (persistent DDIM loop, one sample split over {Cc} CUs)" if spc == 1 else
+                 f"k_den_cluster_ms (persistent loop, clusters of {Cc} CUs that own {spc} samples each)")
     else:
         exe_bytes = exe_cu = den_executed_bytes(den, B, 1, n_infer)
         cus = min(B, 256)                               # one workgroup (one CU) per sample chain
@@ -569,7 +570,7 @@ def main():
                                       + (f", {S} batches in flight per GPU" if S > 1 else "") + (", hipGraph replay" if args.graph else "")},
             "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.weights, B, n_infer, Cc),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.weights, B, n_infer, Cc if spc == 1 else 0) if spc == 1 else None,
                          "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of this configuration; a committed constant, not observed in this run)",
                          "ms_per_launch": round(loop_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                          # what the CUs actually stream (from L2 / Infinity Cache, never HBM: the image is 9-20 MB) and how close

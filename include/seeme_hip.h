@@ -234,8 +234,14 @@ typedef struct {
     void* xchg; size_t xchg_bytes;
     int query;                           /* 0: image packed for ONE condition token (ca term from seeme_denoiser_ca_tables); 1: for two
                                           * (units of ca_block.query / proj_out included, one more exchange per layer) */
+    int samples;                         /* 0 / 1: one sample per cluster (k_den_cluster).  2..8: the large-batch form (k_den_cluster_ms,
+                                          * csrc/den_cluster_ms.inc.hip): a cluster owns up to `samples` chains that share its weight stream
+                                          * (two MFMA A rows per sample, wave s = epilogue wave of sample s): fp16 image, C = 4 or 8, one
+                                          * condition token, one table row per step; ceil(B / samples) rounded up to 8 clusters x C <= CUs;
+                                          * xchg >= seeme_den_cluster_ms_xchg_bytes(B, C, samples) */
 } SeemeDenCluster;
 size_t seeme_den_cluster_xchg_bytes(int B, int C);
+size_t seeme_den_cluster_ms_xchg_bytes(int B, int C, int samples);
 /* out[0] units per (layer, CU) incl. padding, [1] bytes per unit, [2] image bytes, [3] wave-loads per unit, [4] k per wave-load,
  * [5..11] first unit of stage A (x half), A (skip half), B, C, D, E, F, [12] of G (ca query), [13] of H (ca proj_out) (-1 when query = 0) */
 int seeme_den_cluster_layout(int C, int wdtype, int query, int64_t* out, int cap);

@@ -89,7 +89,7 @@ class SampleArgs(C.Structure):
 
 class DenCluster(C.Structure):
     _fields_ = [("wgc", fp), ("wdtype", C.c_int), ("vpc", fp), ("C", C.c_int), ("placement", C.c_int), ("flags", C.c_int),
-                ("xchg", fp), ("xchg_bytes", C.c_size_t), ("query", C.c_int)]
+                ("xchg", fp), ("xchg_bytes", C.c_size_t), ("query", C.c_int), ("samples", C.c_int)]
 
 
 class SmplModel(C.Structure):
@@ -172,6 +172,7 @@ _SIGNATURES = {
     "seeme_denoiser_sample": (C.c_int, [C.POINTER(DenoiserWeights), C.POINTER(SampleArgs), fp]),
     "seeme_denoiser_sample_cluster": (C.c_int, [C.POINTER(DenoiserWeights), C.POINTER(DenCluster), C.POINTER(SampleArgs), fp]),
     "seeme_den_cluster_xchg_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "seeme_den_cluster_ms_xchg_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "seeme_den_cluster_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "seeme_den_train_layout": (C.c_int, [C.POINTER(C.c_int64), C.c_int]),
     "seeme_den_train_pack": (C.c_int, [fp, fp, fp, fp, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.c_int, fp, fp]),

@@ -74,6 +74,7 @@ struct ClArgs {
     unsigned long long* xg;      // granules (behind the header)
     unsigned* hdr;
     int placement, flags, clusters;
+    int spc;                     // k_den_cluster_ms: samples per cluster (<= 8)
 };
 
 // ---- one unit of the weight stream -> its ring slot
@@ -98,11 +99,12 @@ __device__ __forceinline__ void cl_issue(ClRing<WT>& ring, int wave, unsigned vo
 
 // ---- GEMV input vectors in LDS.  16-bit weights: MFMA A-operand fragments [k-block][k-group 4][row 4][8 halves], row p =
 // part p of the fp32 value (put_x); fp32 weights: the plain fp32 vector.
-struct ClX { const char* base; int foff; };
+struct ClX { const char* base; int foff; int kbs; };     // kbs: bytes per k-block of the fragment buffer (rows x 4 k-groups x 16 B)
 template <typename WT>
 __device__ __forceinline__ ClX cl_xin(const float* buf, int lane) {
     ClX x; x.base = reinterpret_cast<const char*>(buf);
     x.foff = WT::MFMA ? ((lane >> 4) * 4 + ((lane & 15) & 3)) * 16 : (lane >> 4) * 16;
+    x.kbs = WT::MFMA ? 256 : 64;
     return x;
 }
 template <typename WT>
@@ -140,11 +142,11 @@ __device__ __forceinline__ void cl_consume(const u32x4 (&slot)[ClW<WT>::UL], con
         constexpr int dummy = 0; (void)dummy;
         const int j = J0 + i, kb = j / TPW - KBOFF, t = j % TPW;
         if constexpr (WT::MFMA) {
-            if (i == 0 || t == 0) a4 = *reinterpret_cast<const uint4*>(x.base + x.foff + kb * 256);
+            if (i == 0 || t == 0) a4 = *reinterpret_cast<const uint4*>(x.base + x.foff + kb * x.kbs);
             if constexpr (WT::HALF) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a4), __builtin_bit_cast(h16x8, slot[i]), acc[t], 0, 0, 0);
             else acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a4), __builtin_bit_cast(bf16x8, slot[i]), acc[t], 0, 0, 0);
         } else {
-            if (i == 0 || t == 0) a4 = *reinterpret_cast<const uint4*>(x.base + x.foff + kb * 64);
+            if (i == 0 || t == 0) a4 = *reinterpret_cast<const uint4*>(x.base + x.foff + kb * x.kbs);
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a4.x), __uint_as_float(slot[i].x), acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a4.y), __uint_as_float(slot[i].y), acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a4.z), __uint_as_float(slot[i].z), acc[t], 0, 0, 0);
@@ -883,6 +885,8 @@ static int launch_den_cluster_c(const ClArgs& ka, int C, bool q, hipStream_t st)
     return seeme_fail("denoiser_sample_cluster: C must be 2, 4 or 8");
 }
 
+static int den_cluster_ms_dispatch(const SeemeDenoiserWeights* w, const SeemeDenCluster* cl, const SeemeSampleArgs* a, ClArgs& ka, hipStream_t st);   // den_cluster_ms.inc.hip
+
 extern "C" int seeme_denoiser_sample_cluster(const SeemeDenoiserWeights* w, const SeemeDenCluster* cl, const SeemeSampleArgs* a, void* stream) {
     if (a->B <= 0) return seeme_fail("denoiser_sample_cluster: B must be > 0");
     if (a->N < 1 || a->N > DCL_MAX_N) return seeme_fail("denoiser_sample_cluster: 1 or 2 condition tokens");
@@ -894,7 +898,8 @@ extern "C" int seeme_denoiser_sample_cluster(const SeemeDenoiserWeights* w, cons
     if (w->ff_sa != FF_SA || w->ff != FF_D) return seeme_fail("denoiser_sample_cluster: built for sa ff 1024 / ffn_dim 128");
     if (a->sched == SEEME_SCHED_NONE && a->steps != 1) return seeme_fail("denoiser_sample_cluster: SCHED_NONE needs steps == 1");
     if (a->steps < 1) return seeme_fail("denoiser_sample_cluster: steps must be >= 1");
-    if (cl->xchg == nullptr || cl->xchg_bytes < seeme_den_cluster_xchg_bytes(a->B, cl->C)) return seeme_fail("denoiser_sample_cluster: exchange buffer too small");
+    const bool ms = cl->samples > 1;
+    if (cl->xchg == nullptr || (!ms && cl->xchg_bytes < seeme_den_cluster_xchg_bytes(a->B, cl->C))) return seeme_fail("denoiser_sample_cluster: exchange buffer too small");
     if (((uintptr_t)cl->xchg & 15) != 0) return seeme_fail("denoiser_sample_cluster: exchange buffer must be 16-byte aligned");
     int64_t lo[14];
     int rc = seeme_den_cluster_layout(cl->C, cl->wdtype, q ? 1 : 0, lo, 14);
@@ -905,8 +910,9 @@ extern "C" int seeme_denoiser_sample_cluster(const SeemeDenoiserWeights* w, cons
     ka.s = *a;
     ka.hdr = (unsigned*)cl->xchg;
     ka.xg = (unsigned long long*)((char*)cl->xchg + DCL_HDR_BYTES);
-    ka.placement = cl->placement; ka.flags = cl->flags; ka.clusters = 0;
+    ka.placement = cl->placement; ka.flags = cl->flags; ka.clusters = 0; ka.spc = 1;
     hipStream_t st = (hipStream_t)stream;
+    if (ms) return den_cluster_ms_dispatch(w, cl, a, ka, st);
     if (cl->wdtype == 0) return launch_den_cluster_c<WF32>(ka, cl->C, q, st);
     if (cl->wdtype == 1) return launch_den_cluster_c<WBF16>(ka, cl->C, q, st);
     if (cl->wdtype == 2) return launch_den_cluster_c<WF16>(ka, cl->C, q, st);

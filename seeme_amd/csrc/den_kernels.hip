@@ -1149,3 +1149,4 @@ extern "C" int seeme_debug_den_times(unsigned long long* host, int n) {
 
 #include "den_train.inc.hip"
 #include "den_cluster.inc.hip"
+#include "den_cluster_ms.inc.hip"

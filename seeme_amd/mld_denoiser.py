@@ -180,6 +180,7 @@ class MldDenoiser(nn.Module):
         # that L2, but every L2 streams the whole 11 MB per step).  Same speed at B = 32 (bench 11.77 k vs 11.79 k seqs/s).
         self.cluster_placement = 1
         self.cluster_flags = 0           # bit 0: write-through granule stores always
+        self.cluster_ms = True           # batches above 32: clusters that own up to 8 samples (k_den_cluster_ms)
         self.pack_xcds = "auto"          # one-CU-per-sample launches: XCDs the working workgroups sit on (_lib.default_xcds); 8 = dealt out
 
         d = self.latent_dim
@@ -389,6 +390,29 @@ class MldDenoiser(nn.Module):
             return 0
         return want if Bp * want <= cus else 0
 
+    def _cluster_plan(self, B: int, N: int, cfg: bool, per_sample: bool, cus: int = 256):
+        """(CUs per cluster, samples per cluster) of this launch; (0, 1) = the one-CU-per-sample kernel.  Up to 64 samples a cluster
+        owns ONE sample (k_den_cluster: 8 CUs up to B = 32, 4 up to 64); above that -- fp16 image, one condition token, one table row
+        per step -- the large-batch form k_den_cluster_ms: 64 clusters of 4 CUs that own ceil(B / 64) <= 8 samples each (B <= 512).
+        Measured at 50 DDIM steps (profiles/r03_g_cluster_ms.txt): B = 128 3.63 ms against 4.30 (2 CUs per sample) / 4.46 (one),
+        B = 256 3.98 against 4.70, B = 512 4.75 against 4.93; 8 CUs x 8 samples is slower (B = 256: 4.99 ms): the exchange volume of
+        a CU grows with C x samples."""
+        Cc = self._cluster_size(B, N, cfg, cus)
+        want = os.environ.get("SEEME_DEN_CLUSTER")
+        want = self.cluster if want is None else (want if want == "auto" else int(want))
+        ms = os.environ.get("SEEME_DEN_CLUSTER_MS", "1") != "0" and self.cluster_ms
+        if (want != "auto" or not ms or B <= 64 or N != 1 or cfg or per_sample or self.num_heads != 1
+                or self.weight_dtype != "fp16"):
+            return Cc, 1
+        forced = os.environ.get("SEEME_DEN_CLUSTER_MS_PLAN")           # "C,samples": measurement only
+        if forced:
+            C4, spc = (int(x) for x in forced.split(","))
+            return C4, spc
+        ncl = (min(int(cus), 256) // 4) // 8 * 8
+        if ncl >= 8 and -(-B // ncl) <= 8:
+            return 4, -(-B // ncl)
+        return Cc, 1
+
     def cluster_status(self):
         """(give-up code, clusters that ran with L2-local granule stores) of the last cluster launch; synchronises."""
         if self._xchg is None:
@@ -451,10 +475,10 @@ class MldDenoiser(nn.Module):
         a.catab = L.ptr(catab)
         a.xcds = L.default_xcds((B + 1) // 2 if (B > 256 and not per_sample and not cfg) else B, self.pack_xcds)
         w = self._weights()
-        Cc = self._cluster_size(B, N, bool(cfg), _device_cus(latents2d.device))
+        Cc, spc = self._cluster_plan(B, N, bool(cfg), bool(per_sample), _device_cus(latents2d.device))
         if Cc:
             img, vpc, code = self._cluster_weights(Cc, N > 1)
-            need = L.lib().seeme_den_cluster_xchg_bytes(B, Cc)
+            need = (L.lib().seeme_den_cluster_ms_xchg_bytes(B, Cc, spc) if spc > 1 else L.lib().seeme_den_cluster_xchg_bytes(B, Cc))
             if self._xchg is None or self._xchg.numel() < need or self._xchg.device != latents2d.device:
                 self._xchg = torch.zeros(need, dtype=torch.uint8, device=latents2d.device)
             cl = L.DenCluster()
@@ -463,6 +487,7 @@ class MldDenoiser(nn.Module):
             cl.flags = int(os.environ.get("SEEME_DEN_CLUSTER_FLAGS", self.cluster_flags))
             cl.xchg, cl.xchg_bytes = self._xchg.data_ptr(), self._xchg.numel()
             cl.query = int(N > 1)
+            cl.samples = spc
             L.check(L.lib().seeme_denoiser_sample_cluster(C.byref(w), C.byref(cl), C.byref(a), L.current_stream()),
                     "seeme_denoiser_sample_cluster")
             return out
