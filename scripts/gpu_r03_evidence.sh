@@ -8,7 +8,13 @@ timeout -k 10 300 python bench.py --cluster 0 --no-cpu-baseline --no-parity-chec
 timeout -k 10 300 python bench.py --weights fp32 --vae fp32 --no-cpu-baseline --no-parity-check > $O/bench_fp32.json 2>/dev/null
 timeout -k 10 300 python bench.py --weights bf16 --no-cpu-baseline > $O/bench_bf16.json 2>/dev/null
 timeout -k 10 300 python bench.py --batch 64 --no-cpu-baseline --no-parity-check > $O/bench_B64.json 2>/dev/null
+timeout -k 10 300 python bench.py --batch 128 --no-cpu-baseline --no-parity-check > $O/bench_B128.json 2>/dev/null
 timeout -k 10 300 python bench.py --batch 256 --no-cpu-baseline --no-parity-check > $O/bench_B256.json 2>/dev/null
+timeout -k 10 300 python bench.py --batch 512 --no-cpu-baseline --no-parity-check > $O/bench_B512.json 2>/dev/null
+SEEME_DEN_CLUSTER_MS=0 timeout -k 10 300 python bench.py --batch 128 --no-cpu-baseline --no-parity-check > $O/bench_B128_no_ms.json 2>/dev/null
+SEEME_DEN_CLUSTER_MS=0 timeout -k 10 300 python bench.py --batch 256 --no-cpu-baseline --no-parity-check > $O/bench_B256_no_ms.json 2>/dev/null
+SEEME_DEN_CLUSTER_MS=0 timeout -k 10 300 python bench.py --batch 512 --no-cpu-baseline --no-parity-check > $O/bench_B512_no_ms.json 2>/dev/null
+SEEME_DEN_CLUSTER_MS=0 timeout -k 10 300 python bench.py --scheduler ddpm --batch 512 --graph --steps 3 --warmup 1 --no-cpu-baseline --no-parity-check > $O/bench_ddpm1000_B512_no_ms.json 2>/dev/null
 timeout -k 10 300 python bench.py --scheduler ddpm --batch 512 --graph --steps 3 --warmup 1 --no-cpu-baseline --no-parity-check > $O/bench_ddpm1000_B512.json 2>/dev/null
 timeout -k 10 300 python bench.py --mode train --steps 20 > $O/bench_train_scene.json 2>/dev/null
 timeout -k 10 300 python bench.py --mode train --train-config gimo --steps 20 > $O/bench_train_gimo.json 2>/dev/null

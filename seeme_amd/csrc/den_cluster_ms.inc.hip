@@ -25,6 +25,11 @@
 #ifndef DCLM_POLL_SLEEP
 #define DCLM_POLL_SLEEP 8     // x 64 cycles between a wave's publish and its first poll
 #endif
+#ifndef DCLM_SENTINEL_FROM
+#define DCLM_SENTINEL_FROM 5  // clusters with at least this many samples first poll ONE granule per (publisher, writing wave) -- a single 8-byte load per
+#endif                        // lane and round -- and sweep once they match: one more round trip per exchange, but eight waves' full sweeps no longer
+                              // circle through the CU's memory queue while they wait (B = 512: 4.94 -> 4.79 ms; B = 128, two samples: 3.60 -> 3.65,
+                              // and k_den_cluster at B = 32: 2.44 -> 2.6 ms -- there the successful poll IS the sweep)
 
 template <int C> struct ClM {
     typedef ClG<C, false> G;
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
     const int es = wave;
     const int bs = b0 + (epi ? es : 0);
     const int ca_R = A.steps;                                    // (one table row per step: trow_per_sample stays on the other kernels)
+    const bool sentinel = ka.spc >= DCLM_SENTINEL_FROM;
     const int g2 = (lane >> 4) * 2;                              // this lane's accumulators hold samples g2 and g2 + 1
 
     float* CONSTV = smem;                        // [768]  query_pos.pe[0], encoder.norm.{weight,bias}
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 u32x4 gv0, gv1, gy0, gy1, gs[G::SC / 2];
                 gy0 = gy1 = u32x4{0u, epoch, 0u, epoch};
                 unsigned spins = 0;
-                {   // cheap wait first: one granule per (publisher, writing wave) -- the first of every 16-column tile of v' (and y) and the first
+                if (sentinel) {   // cheap wait first: one granule per (publisher, writing wave) -- the first of every 16-column tile of v' (and y) and the first
                     // score -- one 8-byte load per lane and round instead of the whole sweep (eight waves poll side by side on this CU)
                     constexpr int TPP = G::S / 16, NS1 = 2 * TPP + 1;               // sentinels per publisher
                     const int sp = lane / NS1, sq = lane - sp * NS1;
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                         if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 2u); break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
-                }
+                } else __builtin_amdgcn_s_sleep(DCLM_POLL_SLEEP);
                 for (;;) {
                     gv0 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_v, 0, 16);
                     gv1 = __builtin_amdgcn_raw_buffer_load_b128(xr_, o_v + 16, 0, 16);
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 const float4 cadd = ld4(A.catab + (((size_t)bs * ca_R + step) * SEEME_DEN_NL + l) * 256 + 4 * lane);
                 float4 sum;
                 unsigned spins = 0;
-                {   // cheap wait first: one granule per (publisher, writing wave): column 0 of the wave's first tile
+                if (sentinel) {   // cheap wait first: one granule per (publisher, writing wave): column 0 of the wave's first tile
                     const bool has = lane < 8 * C;
                     const unsigned so = (unsigned)((G::G_X2 + (lane >> 3) * 256 + (lane & 7) * 32) * 8);
                     __builtin_amdgcn_s_sleep(DCLM_POLL_SLEEP);
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                         if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 4u); break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
-                }
+                } else __builtin_amdgcn_s_sleep(DCLM_POLL_SLEEP);
                 for (;;) {
                     u32x4 g[C][2];
 #pragma unroll
