@@ -517,8 +517,10 @@ def test_sampling_kernel_variants(dev, wd, tol, H, N, cfg):
 @pytest.mark.parametrize("wd", ["fp32", "fp16"])
 def test_large_batch_pairs_match_single_chains(dev, wd):
     """Batches above 256 run two independent samples per workgroup (one weight stream); the result must equal the
-    one-sample-per-workgroup path (itself pinned to the oracle above).  B odd: the last workgroup has one sample."""
+    one-sample-per-workgroup path (itself pinned to the oracle above).  B odd: the last workgroup has one sample.
+    (k_den_sample on both sides: the cluster kernels have their own tests.)"""
     den = make_den(dev, weight_dtype=wd)
+    den.cluster = 0
     g = torch.Generator(device="cpu").manual_seed(7)
     B, steps = 2 * 256 + 3, 4
     lat = torch.randn(B, 1, 256, generator=g).to(dev)
