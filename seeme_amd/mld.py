@@ -40,6 +40,17 @@ from .smpl import SMPL
 
 
 # ----------------------------------------------------------------------------- losses / metrics
+_WARNED = set()
+
+
+def _warn_once(key: str, msg: str) -> None:
+    """Fallbacks onto the autograd twins are announced once per process (they used to be silent)."""
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 class MLDLosses:
     """mld/models/losses/mld.py:10-176 without torchmetrics: running sums + the weighted total."""
 
@@ -416,6 +427,10 @@ class MLD(nn.Module):
             if self.hip_backward and noisy.is_cuda and hip_train_supported(self.denoiser, encoder_hidden_states.shape[0]):
                 noise_pred = denoiser_forward_hip_train(self.denoiser, noisy, timesteps, encoder_hidden_states)  # HIP fwd + bwd
             else:
+                if self.hip_backward and noisy.is_cuda:
+                    _warn_once("denoiser", "stage-2 training of this denoiser configuration (more than one attention head, or a shape the "
+                               "hand-written backward does not cover) runs on the PyTorch-autograd twin (seeme_amd/denoiser_autograd.py): correct, "
+                               "several times slower than the HIP forward/backward")
                 noise_pred = denoiser_forward_torch(self.denoiser, noisy, timesteps, encoder_hidden_states)  # autograd twin
         else:
             noise_pred = self.denoiser(sample=noisy, timestep=timesteps, encoder_hidden_states=encoder_hidden_states,
@@ -485,6 +500,8 @@ class MLD(nn.Module):
             return None
         from .vae_train import VaeTrainer
         if not VaeTrainer.supported(self.vae, T):
+            _warn_once("vae", "stage-1 training of this VAE configuration (more than one attention head, or more than 512 tokens) runs on the "
+                       "PyTorch-autograd twin (seeme_amd/vae_autograd.py): correct, several times slower than the HIP forward/backward")
             return None
         t = getattr(self, "_vae_tr", None)
         if t is None or t.stale():
