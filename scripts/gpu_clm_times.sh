@@ -2,6 +2,6 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out
 export SEEME_HIP_LIB=$PWD/seeme_amd/libseeme_hip_dbg.so
-for B in ${1:-64 256 512}; do
+for B in ${1:-128 256 512}; do
   SEEME_DEN_CLUSTER=auto timeout -k 10 120 python scripts/cl_times.py fp16 $B 2>&1 | grep -v amdgpu.ids
 done | tee gpurun_out/clm_times.txt

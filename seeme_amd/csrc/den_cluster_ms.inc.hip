@@ -18,9 +18,8 @@
 // and the per-layer vector operands are kept in a COMPACT block (only the slices this CU reads: 2 944 floats instead of 6 272 at C = 4)
 // with the samples' K slices behind it; a sample's V' row and its tabulated ca term are read from global memory by its epilogue wave
 // right before it waits for an exchange.  109 KB (C = 4) / 98 KB (C = 8) of LDS.
-// Measured (50 DDIM steps, profiles/r03_g_cluster_ms.txt): B = 128 3.63 ms (k_den_cluster with 2 CUs per sample 4.30, k_den_sample 4.46),
-// B = 256 3.98 (4.70), B = 512 4.75 (4.93): what a sample adds to a cluster is its exchange traffic (4 x 2 KB sweeps per X2, all eight
-// waves polling through the CU's one memory queue), about 4 us per step and sample.
+// Measured (50 DDIM steps, profiles/r03_g_cluster_ms.txt): B = 128 3.44 ms (k_den_cluster with 2 CUs per sample 4.30, k_den_sample 4.46),
+// B = 256 3.66 (4.70), B = 512 4.37 (4.92); DESIGN.md section 5.1b has the three stages that led here and what bounds it now (the exchanges).
 
 #ifndef DCLM_POLL_SLEEP
 #define DCLM_POLL_SLEEP 8     // x 64 cycles between a wave's publish and its first poll
@@ -30,6 +29,20 @@
 #endif                        // lane and round -- and sweep once they match: one more round trip per exchange, but eight waves' full sweeps no longer
                               // circle through the CU's memory queue while they wait (B = 512: 4.94 -> 4.79 ms; B = 128, two samples: 3.60 -> 3.65,
                               // and k_den_cluster at B = 32: 2.44 -> 2.6 ms -- there the successful poll IS the sweep)
+
+#ifndef DCLM_WIN
+#define DCLM_WIN 1            // 1: every unit of the weight stream is requested inside an exchange / vector-algebra window (below); 0: inline, as consumed
+#endif
+// The windowed schedule.  Requested as consumed (k_den_cluster's inline schedule) the stream is exposed time: a 1-KiB wave-request costs the CU's
+// address path 16+ cycles, the issuing wave waits its turn, and at 608-700 KB per layer and CU (C = 4) that is 26 k of a layer's 41 k cycles.  Here
+// every wave is busy in every phase, so there are no idle waves to do the requesting -- but every wave has dead time of its own: between
+// publishing and the first poll of an exchange, and behind its sweep.  Each wave requests ITS eighth of the coming units there:
+//   W1A after the X1 publish (stage B's units), W1B behind the X1 sweep (stage C's), W2A after the X2 publish (D, E), W2B behind its sweep (F),
+//   W3 in the ffn epilogue (next layer's A, x half), AF after stage F (next layer's A, skip half).  Ring slot of unit U = U % 4: a unit goes
+//   out only after unit U - 4 was consumed (C = 4: A 0 1 | AS 2 3 | B 4 5 | C 6 7 | D 8 | E 9 | F 10 11;  C = 8: A 0 | AS 1 | B 2 | C 3 | D 4 | E 5 | F 6 7).
+template <int C> struct ClmSched;
+template <> struct ClmSched<4> { typedef ClSeq<4, 5> W1A; typedef ClSeq<6, 7> W1B; typedef ClSeq<8, 9> W2A; typedef ClSeq<10, 11> W2B; typedef ClSeq<12, 13> W3; typedef ClSeq<14, 15> AF; };
+template <> struct ClmSched<8> { typedef ClSeq<2, 3> W1A; typedef ClSeq<4> W1B; typedef ClSeq<5> W2A; typedef ClSeq<6> W2B; typedef ClSeq<7> W3; typedef ClSeq<8, 9> AF; };
 
 template <int C> struct ClM {
     typedef ClG<C, false> G;
@@ -137,7 +150,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
     constexpr bool Q = false;
     constexpr int MS = M::MS;
     constexpr int A_DEF0 = cl_clamp(2 * G::TA - W::RU, 0, 2 * G::TA);
-    constexpr int A_INL0 = cl_clamp(A_DEF0, 0, G::TA), A_INL1 = cl_clamp(A_DEF0 - G::TA, 0, G::TA), C_INL = cl_clamp(G::TB - W::RU, 0, G::TB);
+    constexpr bool WIN = DCLM_WIN != 0;
+    constexpr int A_INL0 = WIN ? 0 : cl_clamp(A_DEF0, 0, G::TA), A_INL1 = WIN ? 0 : cl_clamp(A_DEF0 - G::TA, 0, G::TA), C_INL = WIN ? 0 : cl_clamp(G::TB - W::RU, 0, G::TB);
+    typedef ClmSched<C> SCH;
     const SeemeSampleArgs& A = ka.s;
     const DenLayout* __restrict__ lay = &ka.lay;
     const float* __restrict__ vp = ka.vp;
@@ -174,6 +189,11 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
     unsigned long long* const xg0 = ka.xg + (size_t)kc * MS * G::G_TOTAL;            // granule blocks of this cluster's samples
     unsigned long long* const xg = xg0 + (size_t)(epi ? es : 0) * G::G_TOTAL;        // ... of this wave's sample
     const __amdgpu_buffer_rsrc_t xr_ = __builtin_amdgcn_make_buffer_rsrc(xg, 0, G::G_TOTAL * 8, 0x00020000);
+    // this wave's sample: its condition-table row and its block of the tabulated ca term, as buffers (scalar base + lane offset: a per-lane
+    // 64-bit address kept across the layer loop is spilled, and its reload drains the vector-memory queue)
+    const __amdgpu_buffer_rsrc_t rs_ct = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.ctab + (size_t)bs * SEEME_CROW), 0, SEEME_CROW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ca = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.catab + (size_t)bs * ca_R * SEEME_DEN_NL * 256), 0,
+                                                                           ca_R * SEEME_DEN_NL * 1024, 0x00020000);
     const unsigned voff = (unsigned)wave * (unsigned)(W::UL * 1024) + (unsigned)lane * 16u;
     const int col = lane & 15;
     const ClX xa = clm_xin(XA, lane), xb = clm_xin(XB, lane), xh = clm_xin(XH, lane);
@@ -230,9 +250,11 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
         const unsigned bb = (unsigned)((0 * C + c) * G::NU) * W::UNIT_BYTES;
         cl_issue<WT, C, Q, 0>(ring, wave, voff, wg, bb, bb, false, false);
         cl_issue<WT, C, Q, 1>(ring, wave, voff, wg, bb, bb, false, false);
-        cl_issue<WT, C, Q, 2>(ring, wave, voff, wg, bb, bb, false, false);
-        cl_issue<WT, C, Q, 3>(ring, wave, voff, wg, bb, bb, false, false);
-        static_assert(W::RU == 4, "prologue issues four units");
+        if constexpr (!WIN || C == 4) {      // (C = 8, windowed: units 2, 3 go out in the first X1 window)
+            cl_issue<WT, C, Q, 2>(ring, wave, voff, wg, bb, bb, false, false);
+            cl_issue<WT, C, Q, 3>(ring, wave, voff, wg, bb, bb, false, false);
+        }
+        static_assert(W::RU == 4, "prologue issues up to four units");
     }
     __syncthreads();
     int cur = 0;
@@ -258,6 +280,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
             const float* const tt_next = A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW;
 
             // ================= A: in_proj' (+ folded skip linear), column-split by dims =================
+            // (measured and not kept: in layers without a skip linear the ring slots of the skip half are idle through stage A, so stage C's units could
+            //  go out at its top instead of in the X1 window -- but then they stand in front of stage A's v' granules: 3.50 -> 3.92 ms at B = 128)
             {
                 f32x4 acc[G::TA];
                 cl_zero<G::TA>(acc);
@@ -309,7 +333,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                     if (lane < G::SC) cl_store_granule(xg + G::G_X1 + c * G::X1_G + 2 * G::S + lane, epoch, pv, local);
                 }
                 // the condition token's V' row of this sample: requested here, lands while the exchange is waited for
-                const float4 cvp = ld4(A.ctab + (size_t)bs * SEEME_CROW + l * 512 + 256 + 4 * lane);
+                const float4 cvp = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_ct, (unsigned)lane * 16u, (unsigned)((l * 512 + 256) * 4), 0));
+                if constexpr (WIN) { __builtin_amdgcn_sched_barrier(0); cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1A{}); }
                 // ---- X1: gather v' (and y), all-reduce the scores
                 const int pub = (4 * lane) / G::S, off = (4 * lane) % G::S;
                 const unsigned o_v = (unsigned)((G::G_X1 + pub * G::X1_G + off) * 8);
@@ -346,6 +371,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                     if (__all(ok != 0u) || dead) break;
                     if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 2u); break; }
                 }
+                if constexpr (WIN) cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1B{});
                 DEN_DBG(0);
                 float sc[3];
 #pragma unroll
@@ -367,16 +393,19 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 if (skip) xr = make_float4(__uint_as_float(gy0.x), __uint_as_float(gy0.z), __uint_as_float(gy1.x), __uint_as_float(gy1.z));
                 xr = wave_ln(f4_add(xr, att), VP + M::O_N1W, VP + M::O_N1B, lane);        // the "values" carry out_proj: residual + norm1
                 clm_put4(XB, es, lane, xr);
+            } else if constexpr (WIN) {        // (waves without a sample: their eighth of both windows)
+                cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1A{});
+                cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1B{});
             }
             __syncthreads(); DEN_DBG(0);
 
             // ================= B: linear1 + ReLU, column-split =================
             nxt.load(0, wave, lane, vp, Ln, tt_next, ln, A, b0, nact, c);
-            cl_refills<WT, C, Q, G::U_A + A_DEF0>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2 * G::TA - A_DEF0>{});   // slots of stage A
+            if constexpr (!WIN) cl_refills<WT, C, Q, G::U_A + A_DEF0>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2 * G::TA - A_DEF0>{});   // slots of stage A
             {
                 f32x4 acc[G::TB];
                 cl_zero<G::TB>(acc);
-                cl_units<WT, C, Q, G::U_B, G::TB, G::TB, 0, 0, G::TB>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB>{});
+                cl_units<WT, C, Q, G::U_B, G::TB, G::TB, 0, 0, (WIN ? 0 : G::TB)>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB>{});
 #pragma unroll
                 for (int t = 0; t < G::TB; ++t) {
                     const int jh = (wave * G::TB + t) * 16 + col;
@@ -405,7 +434,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
             if (epi) {
                 const unsigned epoch = e2;
                 // the tabulated ca_block term of this (sample, step, layer): requested here, lands while the exchange is waited for
-                const float4 cadd = ld4(A.catab + (((size_t)bs * ca_R + step) * SEEME_DEN_NL + l) * 256 + 4 * lane);
+                const float4 cadd = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_ca, (unsigned)lane * 16u, (unsigned)((step * SEEME_DEN_NL + l) * 1024), 0));
+                if constexpr (WIN) { __builtin_amdgcn_sched_barrier(0); cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2A{}); }
                 float4 sum;
                 unsigned spins = 0;
                 if (sentinel) {   // cheap wait first: one granule per (publisher, writing wave): column 0 of the wave's first tile
@@ -438,22 +468,26 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                     if (__all(ok != 0u) || dead) break;
                     if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 4u); break; }
                 }
+                if constexpr (WIN) cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2B{});
                 DEN_DBG(0);
                 // + bias, residual, norm2, + the tabulated ca_block term (one condition token: seeme_denoiser_ca_tables)
                 xr = wave_ln(f4_add(xr, f4_add(sum, ld4(VP + M::O_L2B + 4 * lane))), VP + M::O_N2W, VP + M::O_N2B, lane);
                 xr = f4_add(xr, cadd);
                 clm_put4(XA, es, lane, xr);
                 st4(RES + es * 256 + 4 * lane, xr);
+            } else if constexpr (WIN) {
+                cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2A{});
+                cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2B{});
             }
             __syncthreads(); DEN_DBG(0);
 
             // ================= D: ffn.linear1 + GELU (replicated) =================
             nxt.load(1, wave, lane, vp, Ln, tt_next, ln, A, b0, nact, c);
-            cl_refills<WT, C, Q, G::U_C + C_INL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB - C_INL>{});       // slots of stage C
+            if constexpr (!WIN) cl_refills<WT, C, Q, G::U_C + C_INL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB - C_INL>{});       // slots of stage C
             {
                 f32x4 acc[1];
                 cl_zero<1>(acc);
-                cl_units<WT, C, Q, G::U_D, 1, 1, 0, 0, 1>(ring, xa, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
+                cl_units<WT, C, Q, G::U_D, 1, 1, 0, 0, (WIN ? 0 : 1)>(ring, xa, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
                 const int jh = wave * 16 + col;
                 const float bh = VP[M::O_F1B + jh];
 #pragma unroll
@@ -466,7 +500,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
             {
                 f32x4 acc[2];
                 cl_zero<2>(acc);
-                cl_units<WT, C, Q, G::U_E, 1, 2, 0, 0, 1>(ring, xh, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
+                cl_units<WT, C, Q, G::U_E, 1, 2, 0, 0, (WIN ? 0 : 1)>(ring, xh, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -474,6 +508,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                         if (g2 + j < nact) PART[(g2 + j) * 256 + (2 * wave + tt) * 16 + col] = clm_out(acc[tt], j);
             }
             __syncthreads(); DEN_DBG(0);
+            if constexpr (WIN) cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W3{});
             if (epi) {
                 const float4 y2 = f4_add(ld4(PART + es * 256 + 4 * lane), ld4(VP + M::O_F2B + 4 * lane));
                 const float4 hh = f4_adaln(wave_ln(y2, VP + M::O_FSNW, VP + M::O_FSNB, lane), ld4(VP + M::O_TSC + 4 * lane), ld4(VP + M::O_TSH + 4 * lane));
@@ -485,7 +520,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
             {
                 f32x4 acc[2];
                 cl_zero<2>(acc);
-                cl_units<WT, C, Q, G::U_F, 2, 2, 0, 0, 2>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2>{});
+                cl_units<WT, C, Q, G::U_F, 2, 2, 0, 0, (WIN ? 0 : 2)>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2>{});
+                if constexpr (WIN) cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::AF{});
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     const int n = (2 * wave + tt) * 16 + col;
@@ -503,7 +539,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 }
             }
             nxt.store(lane, STGN);
-            cl_refills<WT, C, Q, G::NU_REAL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::NU - G::NU_REAL>{});   // (phantom units)
+            if constexpr (!WIN) cl_refills<WT, C, Q, G::NU_REAL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::NU - G::NU_REAL>{});   // (phantom units)
             __syncthreads(); DEN_DBG(0);
             if (l + 1 < SEEME_DEN_NL) {
                 if (epi && !nskip) xr = ld4(RES + es * 256 + 4 * lane);               // residual of the next layer's attention

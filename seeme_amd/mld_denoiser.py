@@ -394,9 +394,9 @@ class MldDenoiser(nn.Module):
         """(CUs per cluster, samples per cluster) of this launch; (0, 1) = the one-CU-per-sample kernel.  Up to 64 samples a cluster
         owns ONE sample (k_den_cluster: 8 CUs up to B = 32, 4 up to 64); above that -- fp16 image, one condition token, one table row
         per step -- the large-batch form k_den_cluster_ms: 64 clusters of 4 CUs that own ceil(B / 64) <= 8 samples each (B <= 512).
-        Measured at 50 DDIM steps (profiles/r03_g_cluster_ms.txt): B = 128 3.63 ms against 4.30 (2 CUs per sample) / 4.46 (one),
-        B = 256 3.98 against 4.70, B = 512 4.75 against 4.93; 8 CUs x 8 samples is slower (B = 256: 4.99 ms): the exchange volume of
-        a CU grows with C x samples."""
+        Measured at 50 DDIM steps (profiles/r03_g_cluster_ms.txt): B = 128 3.44 ms against 4.30 (2 CUs per sample) / 4.46 (one),
+        B = 256 3.66 against 4.70, B = 512 4.37 against 4.92; 8 CUs x 8 samples is slower: the exchange volume of a CU grows with
+        C x samples."""
         Cc = self._cluster_size(B, N, cfg, cus)
         want = os.environ.get("SEEME_DEN_CLUSTER")
         want = self.cluster if want is None else (want if want == "auto" else int(want))
