@@ -391,26 +391,29 @@ class MldDenoiser(nn.Module):
         return want if Bp * want <= cus else 0
 
     def _cluster_plan(self, B: int, N: int, cfg: bool, per_sample: bool, cus: int = 256):
-        """(CUs per cluster, samples per cluster) of this launch; (0, 1) = the one-CU-per-sample kernel.  Up to 64 samples a cluster
-        owns ONE sample (k_den_cluster: 8 CUs up to B = 32, 4 up to 64); above that -- fp16 image, one condition token, one table row
-        per step -- the large-batch form k_den_cluster_ms: 64 clusters of 4 CUs that own ceil(B / 64) <= 8 samples each (B <= 512).
-        Measured at 50 DDIM steps (profiles/r03_g_cluster_ms.txt): B = 128 3.44 ms against 4.30 (2 CUs per sample) / 4.46 (one),
-        B = 256 3.66 against 4.70, B = 512 4.37 against 4.92; 8 CUs x 8 samples is slower: the exchange volume of a CU grows with
-        C x samples."""
+        """(CUs per cluster, samples per cluster) of this launch; (0, 1) = the one-CU-per-sample kernel.  Up to 32 samples a cluster of
+        8 CUs owns ONE sample (k_den_cluster, windowed schedule); above that -- fp16 image, one condition token, one table row per step --
+        the large-batch form k_den_cluster_ms: 32 clusters of 8 CUs with two samples each up to B = 64, then 64 clusters of 4 CUs that own
+        ceil(B / 64) <= 8 samples each (B <= 512).  Measured at 50 DDIM steps (profiles/r03_g_cluster_ms.txt): B = 64 3.09 ms against
+        3.23 (4 CUs per sample), B = 128 3.44 against 4.30 (2 CUs per sample) / 4.46 (one), B = 256 3.66 against 4.70, B = 512 4.37
+        against 4.92; 8 CUs x 4 or 8 samples is slower: the exchange volume of a CU grows with C x samples."""
         Cc = self._cluster_size(B, N, cfg, cus)
         want = os.environ.get("SEEME_DEN_CLUSTER")
         want = self.cluster if want is None else (want if want == "auto" else int(want))
         ms = os.environ.get("SEEME_DEN_CLUSTER_MS", "1") != "0" and self.cluster_ms
-        if (want != "auto" or not ms or B <= 64 or N != 1 or cfg or per_sample or self.num_heads != 1
+        if (want != "auto" or not ms or B <= 32 or N != 1 or cfg or per_sample or self.num_heads != 1
                 or self.weight_dtype != "fp16"):
             return Cc, 1
-        forced = os.environ.get("SEEME_DEN_CLUSTER_MS_PLAN")           # "C,samples": measurement only
+        forced = os.environ.get("SEEME_DEN_CLUSTER_MS_PLAN")           # "C,samples" (samples >= 2): measurement only
         if forced:
             C4, spc = (int(x) for x in forced.split(","))
             return C4, spc
-        ncl = (min(int(cus), 256) // 4) // 8 * 8
+        cus = min(int(cus), 256)
+        if B <= 64 and cus >= 256:
+            return 8, 2
+        ncl = (cus // 4) // 8 * 8
         if ncl >= 8 and -(-B // ncl) <= 8:
-            return 4, -(-B // ncl)
+            return 4, max(2, -(-B // ncl))
         return Cc, 1
 
     def cluster_status(self):

@@ -1018,10 +1018,11 @@ def test_auto_cluster_policy(dev):
     assert [den._cluster_size(32, 1, False, cus=c) for c in (256, 128, 64, 32)] == [8, 4, 2, 0]
     # the plan: (CUs per cluster, samples per cluster).  fp32 image: one sample per cluster as above
     assert [den._cluster_plan(B, 1, False, False) for B in (32, 64, 65, 128, 129)] == [(8, 1), (4, 1), (2, 1), (2, 1), (0, 1)]
-    # fp16 image, above 64 samples: 64 clusters of 4 CUs with ceil(B / 64) samples each, up to B = 512
+    # fp16 image, above 32 samples: 32 clusters of 8 CUs with two samples each up to B = 64, then 64 clusters of 4 CUs with ceil(B / 64)
+    # samples each, up to B = 512
     d16 = make_den(dev, weight_dtype="fp16")
-    assert [d16._cluster_plan(B, 1, False, False) for B in (32, 64, 65, 128, 129, 256, 257, 512, 513)] == \
-        [(8, 1), (4, 1), (4, 2), (4, 2), (4, 3), (4, 4), (4, 5), (4, 8), (0, 1)]
+    assert [d16._cluster_plan(B, 1, False, False) for B in (32, 33, 64, 65, 128, 129, 256, 257, 512, 513)] == \
+        [(8, 1), (8, 2), (8, 2), (4, 2), (4, 2), (4, 3), (4, 4), (4, 5), (4, 8), (0, 1)]
     # ... not for two condition tokens, CFG pairs, per-sample timesteps, or when switched off
     assert d16._cluster_plan(128, 2, False, False) == (2, 1) and d16._cluster_plan(128, 1, True, False) == (0, 1)
     assert d16._cluster_plan(128, 1, False, True) == (2, 1)
@@ -1029,11 +1030,11 @@ def test_auto_cluster_policy(dev):
     assert d16._cluster_plan(128, 1, False, False) == (2, 1)
 
 
-@pytest.mark.parametrize("B,sched", [(100, "ddim"), (130, "ddpm"), (512, "ddim")])
+@pytest.mark.parametrize("B,sched", [(50, "ddim"), (100, "ddim"), (130, "ddpm"), (512, "ddim")])
 def test_cluster_ms_equals_one_sample_cluster(dev, B, sched):
     """k_den_cluster_ms (csrc/den_cluster_ms.inc.hip; batches above 64: a cluster of 4 CUs owns up to 8 samples, two MFMA A rows each)
-    against k_den_cluster with the same C on the same samples, 64 at a time: the same weight image, the same exchanges, the same order
-    of every addition -- bit-identical, for ragged last clusters (B = 100: 50 clusters of 2; B = 130: 3 per cluster, the last one 1),
+    against k_den_cluster with the same C on the same samples, 256 / C at a time: the same weight image, the same exchanges, the same order
+    of every addition -- bit-identical, for 8-CU clusters with two samples (B = 50), ragged last clusters (B = 100: 50 clusters of 2; B = 130: 3 per cluster, the last one 1),
     the full 8 samples per cluster (B = 512), DDIM and DDPM with injected step noise (mld.py:467-497); and within fp16 rounding of the
     one-CU-per-sample kernel, whose image keeps the skip linears unfolded."""
     den = make_den(dev, weight_dtype="fp16")
@@ -1044,17 +1045,18 @@ def test_cluster_ms_equals_one_sample_cluster(dev, B, sched):
     torch.manual_seed(B)
     lat, cond = torch.randn(B, 1, 256, device=dev), torch.randn(B, 1, 256, device=dev)
     noise = torch.randn(steps, B, 256, device=dev) if sched == "ddpm" else None
-    plan = den._cluster_plan(B, 1, False, False)
-    assert plan == (4, -(-B // 64))
+    Cc, spc = den._cluster_plan(B, 1, False, False)
+    assert (Cc, spc) == ((8, 2) if B <= 64 else (4, -(-B // 64)))
     z = den.sample_loop(lat, cond, sch, step_noise=noise)
     z2 = den.sample_loop(lat, cond, sch, step_noise=noise)
     torch.cuda.synchronize()
     assert den.cluster_status()[0] == 0
     assert torch.equal(z, z2)
     den.cluster_ms = False
-    _with_cluster(den, 4, 1)
-    ref = torch.cat([den.sample_loop(lat[i:i + 64].contiguous(), cond[i:i + 64].contiguous(), sch,
-                                     step_noise=None if noise is None else noise[:, i:i + 64].contiguous()) for i in range(0, B, 64)], 1)
+    _with_cluster(den, Cc, 1)
+    ch = 256 // Cc
+    ref = torch.cat([den.sample_loop(lat[i:i + ch].contiguous(), cond[i:i + ch].contiguous(), sch,
+                                     step_noise=None if noise is None else noise[:, i:i + ch].contiguous()) for i in range(0, B, ch)], 1)
     torch.cuda.synchronize()
     assert torch.equal(z, ref), float((z - ref).abs().max())
     _with_cluster(den, 0)
