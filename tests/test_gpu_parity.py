@@ -1064,6 +1064,25 @@ def test_cluster_ms_equals_one_sample_cluster(dev, B, sched):
     assert rel_err(z.cpu().numpy(), one.cpu().numpy()) < 1e-3
 
 
+def test_single_forward_stays_off_the_large_batch_kernel(dev):
+    """MldDenoiser.forward (one step, no scheduler; mld_denoiser.py:151-244) hands the kernel one table row PER SAMPLE (scalar and vector
+    timesteps alike), which k_den_cluster_ms does not take: at a batch size whose sampling loop runs on it, forward() stays on the
+    one-sample kernels and equals their result on the same samples in smaller batches."""
+    den = make_den(dev, weight_dtype="fp16")
+    torch.manual_seed(21)
+    B = 150
+    x, c = torch.randn(B, 1, 256, device=dev), torch.randn(1, B, 256, device=dev)
+    assert den._cluster_plan(B, 1, False, False) == (4, 3) and den._cluster_plan(B, 1, False, True) == (0, 1)
+    tv = torch.randint(0, 1000, (B,), device=dev)
+    for t in (torch.tensor(417), tv):
+        den.cluster = "auto"
+        y = den(sample=x, timestep=t, encoder_hidden_states=c)[0]
+        den.cluster = 0
+        ref = torch.cat([den(sample=x[i:i + 64].contiguous(), timestep=t if t.dim() == 0 else t[i:i + 64].contiguous(),
+                             encoder_hidden_states=c[:, i:i + 64].contiguous())[0] for i in range(0, B, 64)], 0)
+        assert torch.equal(y, ref), float((y - ref).abs().max())
+
+
 @pytest.mark.parametrize("Cc", [8, 4, 2])
 def test_cluster_sampler_two_condition_tokens(dev, Cc):
     """k_den_cluster with scene + interactee (N = 2: the reference's shipped config_mld_egobody.yaml:114): the ca_block keeps its query
