@@ -207,20 +207,28 @@ constexpr int cl_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? h
 #define DCL_POLL_SLEEP 12
 #endif
 template <int... Us> using ClSeq = std::integer_sequence<int, Us...>;
-template <int C, bool MF, bool Q> struct ClSched { static constexpr bool WIN = false; static constexpr int PRO = 0; typedef ClSeq<> W1A, W1B, W2A, W2B, W3, PF, AF; };
+template <int C, bool MF, bool Q> struct ClSched { static constexpr bool WIN = false; static constexpr int PRO = 0; typedef ClSeq<> W1A, W1B, W2A, W2B, WXA, WXB, W3, PF, AF; };
 #ifndef DCL_SCHED
 #define DCL_SCHED 9
 #endif
+#ifndef DCL_SCHED_Q
+#define DCL_SCHED_Q 1      // the windowed schedule also for two condition tokens (C = 8, 16-bit images)
+#endif
 #if DCL_SCHED == 8      // "early": every unit one window ahead of the inline scheme; the next layer's B and C still go out inline in phase F (PRO: units in flight at a layer's start)
-template <> struct ClSched<8, true, false> { static constexpr bool WIN = true; static constexpr int PRO = 4; typedef ClSeq<4> W1A; typedef ClSeq<5> W1B; typedef ClSeq<6> W2A; typedef ClSeq<7> W2B;
+template <> struct ClSched<8, true, false> { static constexpr bool WIN = true; static constexpr int PRO = 4; typedef ClSeq<> WXA, WXB; typedef ClSeq<4> W1A; typedef ClSeq<5> W1B; typedef ClSeq<6> W2A; typedef ClSeq<7> W2B;
                                              typedef ClSeq<8> W3; typedef ClSeq<9> PF; typedef ClSeq<10, 11> AF; };
 #elif DCL_SCHED == 9    // "just in time": a unit goes out in the window before the phase that consumes it; only the next layer's A is requested inline (after F)
-template <> struct ClSched<8, true, false> { static constexpr bool WIN = true; static constexpr int PRO = 2; typedef ClSeq<2, 3> W1A; typedef ClSeq<4> W1B; typedef ClSeq<5> W2A; typedef ClSeq<6> W2B;
+template <> struct ClSched<8, true, false> { static constexpr bool WIN = true; static constexpr int PRO = 2; typedef ClSeq<> WXA, WXB; typedef ClSeq<2, 3> W1A; typedef ClSeq<4> W1B; typedef ClSeq<5> W2A; typedef ClSeq<6> W2B;
                                              typedef ClSeq<7> W3; typedef ClSeq<> PF; typedef ClSeq<8, 9> AF; };
 #elif DCL_SCHED == 10   // as 9, with the second exchange window taking two units as well, so that only the skip layers' A1 is left inline
-template <> struct ClSched<8, true, false> { static constexpr bool WIN = true; static constexpr int PRO = 2; typedef ClSeq<2, 3> W1A; typedef ClSeq<4> W1B; typedef ClSeq<5, 6> W2A; typedef ClSeq<7> W2B;
+template <> struct ClSched<8, true, false> { static constexpr bool WIN = true; static constexpr int PRO = 2; typedef ClSeq<> WXA, WXB; typedef ClSeq<2, 3> W1A; typedef ClSeq<4> W1B; typedef ClSeq<5, 6> W2A; typedef ClSeq<7> W2B;
                                              typedef ClSeq<8> W3; typedef ClSeq<> PF; typedef ClSeq<9> AF; };
 #endif
+// Two condition tokens (Q: the ca_block keeps its query G and proj_out H stages and a third exchange X3), just in time as schedule 9:
+//   units A 0 | AS 1 | B 2 | C 3 | G 4 | H 5 6 | D 7 | E 8 | F 9 10 | (11 phantom);  ring slot = U % 4
+//   W1A B C | W1B G | W2A H0 | W2B H1 | WXA (X3 published) D | WXB (X3 swept) E | W3 (ffn epilogue) F0 F1 | after F: next A, AS
+template <> struct ClSched<8, true, true> { static constexpr bool WIN = DCL_SCHED_Q != 0; static constexpr int PRO = 2; typedef ClSeq<2, 3> W1A; typedef ClSeq<4> W1B; typedef ClSeq<5> W2A; typedef ClSeq<6> W2B;
+                                            typedef ClSeq<7> WXA; typedef ClSeq<8> WXB; typedef ClSeq<9, 10> W3; typedef ClSeq<> PF; typedef ClSeq<12, 13> AF; };
 template <typename WT, int C, bool Q, int... Us>
 __device__ __forceinline__ void cl_issue_seq(ClRing<WT>& ring, int wave, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned bc, unsigned bn,
                                              bool sc, bool sn, ClSeq<Us...>) {
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
 
             if constexpr (Q) {
                 // ================= G: ca_block.query, column-split by dims (waves < S / 16 own one tile each) -> X3 =================
-                cl_refills<WT, C, Q, G::U_C + C_INL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB - C_INL>{});   // slots of stage C
+                if constexpr (!WIN) cl_refills<WT, C, Q, G::U_C + C_INL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB - C_INL>{});   // slots of stage C
                 {
                     f32x4 acc[1];
                     cl_zero<1>(acc);
@@ -674,6 +682,12 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                         for (int n = 0; n < DCL_MAX_N; ++n) pv = lane == 2 + n ? tn[n] : pv;
                         if (lane < 8) cl_store_granule(xg + G::G_X3 + c * 8 + lane, epoch, pv, local);
                     }
+                    if constexpr (WIN) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::WXA{});
+                        if (lane == 0) cl_flag_set(FLG + 1, e3);
+                        __builtin_amdgcn_s_sleep(DCL_POLL_SLEEP);
+                    }
                     const unsigned o3 = (unsigned)((G::G_X3 + (lane % C) * 8) * 8);
                     u32x4 g3[4];
                     unsigned spins = 0;
@@ -685,6 +699,10 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                         for (int j = 0; j < 4; ++j) ok &= cl_tags_ok(g3[j], epoch);
                         if (__all(ok != 0u) || dead) break;
                         if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 8u); break; }
+                    }
+                    if constexpr (WIN) {
+                        cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::WXB{});
+                        if (lane == 0) cl_flag_set(FLG + 2, e3);
                     }
                     DEN_DBG(0);
                     // lane group of C publishers: [m, l, t_0 .. ] of publisher lane % C
@@ -713,15 +731,20 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
                     // StylizationBlock (mdiff_transformer.py:152-163): SiLU(LN(y) (1 + scale) + shift) -> proj_out.out_layers
                     const float4 hh = f4_adaln(wave_ln(y, v_csnw, v_csnb, lane), ld4(TTS + 512 + 4 * lane), ld4(TTS + 768 + 4 * lane));
                     put_x<WT, 1>(XB, 0, 0, lane, f4_silu(hh));
+                } else if constexpr (WIN) {
+                    cl_flag_wait(FLG + 1, e3);
+                    cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::WXA{});
+                    cl_flag_wait(FLG + 2, e3);
+                    cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::WXB{});
                 }
                 __syncthreads(); DEN_DBG(0);
                 // ================= H: ca_block.proj_out.out_layers + residual (replicated) =================
-                cl_refills<WT, C, Q, G::U_G>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});                    // slot of stage G
+                if constexpr (!WIN) cl_refills<WT, C, Q, G::U_G>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});                    // slot of stage G
                 nxt.load(2, wave, lane, vp, Ln, tt_next, ln, A, b, c, ca_next, ca_R);
                 {
                     f32x4 acc[2];
                     cl_zero<2>(acc);
-                    cl_units<WT, C, Q, G::U_H, 2, 2, 0, 0, 2>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2>{});
+                    cl_units<WT, C, Q, G::U_H, 2, 2, 0, 0, (WIN ? 0 : 2)>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2>{});
                     if (lane < 32) {
                         const int n = (2 * wave + (lane >> 4)) * 16 + col;
                         const float x3 = RES[n] + ((lane & 16) ? cl_out<WT>(acc[1]) : cl_out<WT>(acc[0])) + v_cao_b[n];
@@ -786,7 +809,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster(const ClArgs ka) {
             }
             nxt.store(lane, STG + (cur ^ 1) * stg_sz);
             // (phantom units that pad the layer program are never consumed: the re-fills they would trigger go out here)
-            cl_refills<WT, C, Q, G::NU_REAL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::NU - G::NU_REAL>{});
+            if constexpr (!WIN) cl_refills<WT, C, Q, G::NU_REAL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::NU - G::NU_REAL>{});
             __syncthreads(); DEN_DBG(0);
             if (l + 1 < SEEME_DEN_NL) {
                 if (epi && !nskip) xr = ld4(RES + 4 * lane);                          // residual of the next layer's attention
