@@ -6,7 +6,7 @@ import numpy as np
 import torch
 from test_gpu_parity import make_den, _sched
 dev = torch.device("cuda:0")
-den = make_den(dev, weight_dtype="fp16")
+den = make_den(dev, weight_dtype=os.environ.get("WD", "fp16"))
 sch = _sched(); sch.set_timesteps(50)
 torch.manual_seed(7)
 lat = torch.randn(512, 1, 256, device=dev); cond = torch.randn(512, 1, 256, device=dev)
@@ -22,5 +22,5 @@ for B in [int(x) for x in (sys.argv[1:] or ["64", "128", "256", "512"])]:
         torch.cuda.synchronize()
         ts.append(ev[0].elapsed_time(ev[1]))
     print(json.dumps({"B": B, "plan": den._cluster_plan(B, 1, False, False), "place": os.environ.get("SEEME_DEN_CLUSTER_PLACE"), "flags": os.environ.get("SEEME_DEN_CLUSTER_FLAGS"),
-                      "lib": os.path.basename(os.environ.get("SEEME_HIP_LIB", "")), "ms": round(float(np.median(ts)), 4), "us_per_step": round(float(np.median(ts)) * 20, 2),
+                      "wd": os.environ.get("WD", "fp16"), "lib": os.path.basename(os.environ.get("SEEME_HIP_LIB", "")), "ms": round(float(np.median(ts)), 4), "us_per_step": round(float(np.median(ts)) * 20, 2),
                       "status": den.cluster_status()}), flush=True)

@@ -211,6 +211,9 @@ template <int C, bool MF, bool Q> struct ClSched { static constexpr bool WIN = f
 #ifndef DCL_SCHED
 #define DCL_SCHED 9
 #endif
+#ifndef DCL_SCHED_C4
+#define DCL_SCHED_C4 1     // ... and for clusters of four CUs
+#endif
 #ifndef DCL_SCHED_Q
 #define DCL_SCHED_Q 1      // the windowed schedule also for two condition tokens (C = 8, 16-bit images)
 #endif
@@ -229,6 +232,14 @@ template <> struct ClSched<8, true, false> { static constexpr bool WIN = true; s
 //   W1A B C | W1B G | W2A H0 | W2B H1 | WXA (X3 published) D | WXB (X3 swept) E | W3 (ffn epilogue) F0 F1 | after F: next A, AS
 template <> struct ClSched<8, true, true> { static constexpr bool WIN = DCL_SCHED_Q != 0; static constexpr int PRO = 2; typedef ClSeq<2, 3> W1A; typedef ClSeq<4> W1B; typedef ClSeq<5> W2A; typedef ClSeq<6> W2B;
                                             typedef ClSeq<7> WXA; typedef ClSeq<8> WXB; typedef ClSeq<9, 10> W3; typedef ClSeq<> PF; typedef ClSeq<12, 13> AF; };
+// Four CUs per sample (16-bit images, 32 < B <= 64): units A 0 1 | AS 2 3 | B 4 5 | C 6 7 | D 8 | E 9 | F 10 11 (the table k_den_cluster_ms uses);
+// with two condition tokens: ... | G 8 | H 9 10 | D 11 | E 12 | F 13 14 | (15 phantom)
+#if DCL_SCHED_C4
+template <> struct ClSched<4, true, false> { static constexpr bool WIN = true; static constexpr int PRO = 4; typedef ClSeq<4, 5> W1A; typedef ClSeq<6, 7> W1B; typedef ClSeq<8, 9> W2A; typedef ClSeq<10, 11> W2B;
+                                             typedef ClSeq<> WXA, WXB; typedef ClSeq<12, 13> W3; typedef ClSeq<> PF; typedef ClSeq<14, 15> AF; };
+template <> struct ClSched<4, true, true> { static constexpr bool WIN = true; static constexpr int PRO = 4; typedef ClSeq<4, 5> W1A; typedef ClSeq<6, 7> W1B; typedef ClSeq<8, 9> W2A; typedef ClSeq<10> W2B;
+                                            typedef ClSeq<11> WXA; typedef ClSeq<12> WXB; typedef ClSeq<13, 14> W3; typedef ClSeq<> PF; typedef ClSeq<16, 17, 18, 19> AF; };
+#endif
 template <typename WT, int C, bool Q, int... Us>
 __device__ __forceinline__ void cl_issue_seq(ClRing<WT>& ring, int wave, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned bc, unsigned bn,
                                              bool sc, bool sn, ClSeq<Us...>) {

@@ -10,8 +10,8 @@
 // pass over the cluster's weight slices serves eight chains (same wave-loads, same MFMAs as for one), wave s is the epilogue wave of
 // sample s (softmax over the 2 + N tokens, the LayerNorms, AdaLN, scheduler step -- eight of them side by side instead of one with
 // seven waves idle), and every sample has its own granule block and its own two exchanges per layer.
-//   32 < B <= 64: C = 8, 32 clusters x 2 samples;   64 < B <= 512: C = 4, 64 clusters x ceil(B / 64) samples   (host policy,
-//   seeme_amd/mld_denoiser.py::_cluster_plan; above two samples 8-CU clusters measure slower: a CU's exchange volume grows with C x samples)
+//   64 < B <= 512: C = 4, 64 clusters x ceil(B / 64) samples   (host policy, seeme_amd/mld_denoiser.py::_cluster_plan; C = 8 is built too and
+//   measures slower: a CU's exchange volume grows with C x samples; up to B = 64 the windowed one-sample kernel on 4 CUs is faster)
 // fp16 weight image (the bench default; two A rows per sample), one condition token (tabulated ca term), one head, no CFG, one
 // timestep row per step: everything else stays on k_den_sample / k_den_cluster.  The weight image, the unit program and the exchange
 // protocol are k_den_cluster's (inline load schedule), results are bit-identical to it; LDS differs: the A-operand buffers hold 16 rows,

@@ -391,12 +391,12 @@ class MldDenoiser(nn.Module):
         return want if Bp * want <= cus else 0
 
     def _cluster_plan(self, B: int, N: int, cfg: bool, per_sample: bool, cus: int = 256):
-        """(CUs per cluster, samples per cluster) of this launch; (0, 1) = the one-CU-per-sample kernel.  Up to 32 samples a cluster of
-        8 CUs owns ONE sample (k_den_cluster, windowed schedule); above that -- fp16 image, one condition token, one table row per step --
-        the large-batch form k_den_cluster_ms: 32 clusters of 8 CUs with two samples each up to B = 64, then 64 clusters of 4 CUs that own
-        ceil(B / 64) <= 8 samples each (B <= 512).  Measured at 50 DDIM steps (profiles/r03_g_cluster_ms.txt): B = 64 3.09 ms against
-        3.23 (4 CUs per sample), B = 128 3.44 against 4.30 (2 CUs per sample) / 4.46 (one), B = 256 3.66 against 4.70, B = 512 4.37
-        against 4.92; 8 CUs x 4 or 8 samples is slower: the exchange volume of a CU grows with C x samples."""
+        """(CUs per cluster, samples per cluster) of this launch; (0, 1) = the one-CU-per-sample kernel.  Up to 64 samples a cluster owns
+        ONE sample (k_den_cluster, windowed schedules: 8 CUs up to B = 32, 4 up to 64); above that -- fp16 image, one condition token,
+        one table row per step -- the large-batch form k_den_cluster_ms: 64 clusters of 4 CUs that own ceil(B / 64) <= 8 samples each
+        (B <= 512).  Measured at 50 DDIM steps (profiles/r03_g_cluster_ms.txt, r03_k_c4_windows.txt): B = 64 2.83 ms (8 CUs x 2 samples
+        3.09), B = 128 3.44 against 4.30 (2 CUs per sample) / 4.46 (one), B = 256 3.66 against 4.70, B = 512 4.37 against 4.92;
+        8 CUs x 4 or 8 samples is slower: the exchange volume of a CU grows with C x samples."""
         Cc = self._cluster_size(B, N, cfg, cus)
         want = os.environ.get("SEEME_DEN_CLUSTER")
         want = self.cluster if want is None else (want if want == "auto" else int(want))
@@ -409,8 +409,8 @@ class MldDenoiser(nn.Module):
             C4, spc = (int(x) for x in forced.split(","))
             return C4, spc
         cus = min(int(cus), 256)
-        if B <= 64 and cus >= 256:
-            return 8, 2
+        if B <= 64 and Cc == 4:
+            return Cc, 1
         ncl = (cus // 4) // 8 * 8
         if ncl >= 8 and -(-B // ncl) <= 8:
             return 4, max(2, -(-B // ncl))

@@ -1018,11 +1018,10 @@ def test_auto_cluster_policy(dev):
     assert [den._cluster_size(32, 1, False, cus=c) for c in (256, 128, 64, 32)] == [8, 4, 2, 0]
     # the plan: (CUs per cluster, samples per cluster).  fp32 image: one sample per cluster as above
     assert [den._cluster_plan(B, 1, False, False) for B in (32, 64, 65, 128, 129)] == [(8, 1), (4, 1), (2, 1), (2, 1), (0, 1)]
-    # fp16 image, above 32 samples: 32 clusters of 8 CUs with two samples each up to B = 64, then 64 clusters of 4 CUs with ceil(B / 64)
-    # samples each, up to B = 512
+    # fp16 image, above 64 samples: 64 clusters of 4 CUs with ceil(B / 64) samples each, up to B = 512
     d16 = make_den(dev, weight_dtype="fp16")
     assert [d16._cluster_plan(B, 1, False, False) for B in (32, 33, 64, 65, 128, 129, 256, 257, 512, 513)] == \
-        [(8, 1), (8, 2), (8, 2), (4, 2), (4, 2), (4, 3), (4, 4), (4, 5), (4, 8), (0, 1)]
+        [(8, 1), (4, 1), (4, 1), (4, 2), (4, 2), (4, 3), (4, 4), (4, 5), (4, 8), (0, 1)]
     # ... not for two condition tokens, CFG pairs, per-sample timesteps, or when switched off
     assert d16._cluster_plan(128, 2, False, False) == (2, 1) and d16._cluster_plan(128, 1, True, False) == (0, 1)
     assert d16._cluster_plan(128, 1, False, True) == (2, 1)
@@ -1030,7 +1029,7 @@ def test_auto_cluster_policy(dev):
     assert d16._cluster_plan(128, 1, False, False) == (2, 1)
 
 
-@pytest.mark.parametrize("B,sched", [(50, "ddim"), (100, "ddim"), (130, "ddpm"), (512, "ddim")])
+@pytest.mark.parametrize("B,sched", [(50, "ddim8"), (100, "ddim"), (130, "ddpm"), (512, "ddim")])
 def test_cluster_ms_equals_one_sample_cluster(dev, B, sched):
     """k_den_cluster_ms (csrc/den_cluster_ms.inc.hip; batches above 64: a cluster of 4 CUs owns up to 8 samples, two MFMA A rows each)
     against k_den_cluster with the same C on the same samples, 256 / C at a time: the same weight image, the same exchanges, the same order
@@ -1039,6 +1038,10 @@ def test_cluster_ms_equals_one_sample_cluster(dev, B, sched):
     one-CU-per-sample kernel, whose image keeps the skip linears unfolded."""
     den = make_den(dev, weight_dtype="fp16")
     steps = 12
+    forced8 = sched == "ddim8"                                   # (8 CUs x 2 samples: built, not what the policy picks)
+    if forced8:
+        sched = "ddim"
+        os.environ["SEEME_DEN_CLUSTER_MS_PLAN"] = "8,2"
     sch = _sched(sched)
     sch.set_timesteps(1000 if sched == "ddpm" else 50)
     sch.timesteps = sch.timesteps[:steps]
@@ -1046,10 +1049,11 @@ def test_cluster_ms_equals_one_sample_cluster(dev, B, sched):
     lat, cond = torch.randn(B, 1, 256, device=dev), torch.randn(B, 1, 256, device=dev)
     noise = torch.randn(steps, B, 256, device=dev) if sched == "ddpm" else None
     Cc, spc = den._cluster_plan(B, 1, False, False)
-    assert (Cc, spc) == ((8, 2) if B <= 64 else (4, -(-B // 64)))
+    assert (Cc, spc) == ((8, 2) if forced8 else (4, -(-B // 64)))
     z = den.sample_loop(lat, cond, sch, step_noise=noise)
     z2 = den.sample_loop(lat, cond, sch, step_noise=noise)
     torch.cuda.synchronize()
+    os.environ.pop("SEEME_DEN_CLUSTER_MS_PLAN", None)
     assert den.cluster_status()[0] == 0
     assert torch.equal(z, z2)
     den.cluster_ms = False
