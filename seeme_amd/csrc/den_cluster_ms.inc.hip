@@ -30,6 +30,12 @@
                               // circle through the CU's memory queue while they wait (B = 512: 4.94 -> 4.79 ms; B = 128, two samples: 3.60 -> 3.65,
                               // and k_den_cluster at B = 32: 2.44 -> 2.6 ms -- there the successful poll IS the sweep)
 
+#ifndef DCLM_IDLE_FLAGS
+#define DCLM_IDLE_FLAGS 1     // waves without a sample request their window share behind sample 0's publish / sweep (words in LDS), not at once
+#endif
+#ifndef DCLM_PUB_ALL
+#define DCLM_PUB_ALL 1        // an epilogue wave's own window requests also wait until every sample of the CU has published
+#endif
 #ifndef DCLM_WIN
 #define DCLM_WIN 1            // 1: every unit of the weight stream is requested inside an exchange / vector-algebra window (below); 0: inline, as consumed
 #endif
@@ -92,6 +98,20 @@ __device__ __forceinline__ void clm_put4(float* buf, int s, int lane, float4 v) 
 // the two samples of a lane's accumulator: lane group g = lane >> 4 holds D rows 4 g .. 4 g + 3 = (hi, lo) of samples 2 g and 2 g + 1
 __device__ __forceinline__ float clm_out(const f32x4& a, int j) {
     return j ? fmaf(a.w, 1.f / DEN_F16_LO_SCALE, a.z) : fmaf(a.y, 1.f / DEN_F16_LO_SCALE, a.x);
+}
+
+// FLG[2] counts the samples whose epilogue wave has published its part of an exchange (ever: nact per exchange).  A window's requests go out
+// only once ALL of this CU's samples have published: requests in the queue in front of another wave's granule stores delay the whole cluster.
+__device__ __forceinline__ void clm_wait_published(const int* f, int target) {
+    while (*(const cl_lds_flag*)f < target) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void clm_published(int* f, int lane, int target) {
+#if DCLM_IDLE_FLAGS
+    if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if DCLM_PUB_ALL
+    clm_wait_published(f, target);
+#endif
+#endif
 }
 
 // one piece (<= 1 KiB) of the NEXT layer's operands per wave and phase k = 0 .. 5: requested at the top of the phase, stored to the other
@@ -219,6 +239,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
         }
     }
     for (int i = tid; i < XZERO / 4; i += DEN_THREADS) st4(XA + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+    if (tid >= 2 && tid < 4) FLG[tid] = 0;                   // window flags (epochs are never 0)
     bool dead = false, local = false;
     if (wave == 0) {
         // first exchange, always write-through: the XCC id of every workgroup of the cluster (sample 0's boot granules)
@@ -276,6 +297,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
             const float* SMP = VP + M::O_SMP + es * G::S;        // this wave's sample: the condition token's K over this CU's dims
             const bool ywave = wave >= 6;
             const unsigned e1 = 1u + 2u * (unsigned)(step * SEEME_DEN_NL + l), e2 = e1 + 1u;
+            const int pub1 = nact * (int)e1, pub2 = nact * (int)e2;   // the LDS count of published samples after X1 / X2 of this layer (FLG[2])
             ClmStage<C> nxt;
             const float* const tt_next = A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW;
 
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 }
                 // the condition token's V' row of this sample: requested here, lands while the exchange is waited for
                 const float4 cvp = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_ct, (unsigned)lane * 16u, (unsigned)((l * 512 + 256) * 4), 0));
-                if constexpr (WIN) { __builtin_amdgcn_sched_barrier(0); cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1A{}); }
+                if constexpr (WIN) { __builtin_amdgcn_sched_barrier(0); clm_published(FLG + 2, lane, pub1); cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1A{}); }
                 // ---- X1: gather v' (and y), all-reduce the scores
                 const int pub = (4 * lane) / G::S, off = (4 * lane) % G::S;
                 const unsigned o_v = (unsigned)((G::G_X1 + pub * G::X1_G + off) * 8);
@@ -371,7 +393,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                     if (__all(ok != 0u) || dead) break;
                     if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 2u); break; }
                 }
-                if constexpr (WIN) cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1B{});
+                if constexpr (WIN) { cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1B{}); if (DCLM_IDLE_FLAGS && wave == 0 && lane == 0) cl_flag_set(FLG + 3, e1); }
                 DEN_DBG(0);
                 float sc[3];
 #pragma unroll
@@ -393,8 +415,11 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 if (skip) xr = make_float4(__uint_as_float(gy0.x), __uint_as_float(gy0.z), __uint_as_float(gy1.x), __uint_as_float(gy1.z));
                 xr = wave_ln(f4_add(xr, att), VP + M::O_N1W, VP + M::O_N1B, lane);        // the "values" carry out_proj: residual + norm1
                 clm_put4(XB, es, lane, xr);
-            } else if constexpr (WIN) {        // (waves without a sample: their eighth of both windows)
+            } else if constexpr (WIN) {        // (waves without a sample: their eighth of both windows -- behind sample 0's publish and sweep, as in
+                                               //  k_den_cluster: requested at once they would stand in front of the epilogue waves' granule stores)
+                if (DCLM_IDLE_FLAGS) clm_wait_published(FLG + 2, pub1);
                 cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1A{});
+                if (DCLM_IDLE_FLAGS) cl_flag_wait(FLG + 3, e1);
                 cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1B{});
             }
             __syncthreads(); DEN_DBG(0);
@@ -435,7 +460,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 const unsigned epoch = e2;
                 // the tabulated ca_block term of this (sample, step, layer): requested here, lands while the exchange is waited for
                 const float4 cadd = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_ca, (unsigned)lane * 16u, (unsigned)((step * SEEME_DEN_NL + l) * 1024), 0));
-                if constexpr (WIN) { __builtin_amdgcn_sched_barrier(0); cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2A{}); }
+                if constexpr (WIN) { __builtin_amdgcn_sched_barrier(0); clm_published(FLG + 2, lane, pub2); cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2A{}); }
                 float4 sum;
                 unsigned spins = 0;
                 if (sentinel) {   // cheap wait first: one granule per (publisher, writing wave): column 0 of the wave's first tile
@@ -468,7 +493,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                     if (__all(ok != 0u) || dead) break;
                     if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 4u); break; }
                 }
-                if constexpr (WIN) cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2B{});
+                if constexpr (WIN) { cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2B{}); if (DCLM_IDLE_FLAGS && wave == 0 && lane == 0) cl_flag_set(FLG + 3, e2); }
                 DEN_DBG(0);
                 // + bias, residual, norm2, + the tabulated ca_block term (one condition token: seeme_denoiser_ca_tables)
                 xr = wave_ln(f4_add(xr, f4_add(sum, ld4(VP + M::O_L2B + 4 * lane))), VP + M::O_N2W, VP + M::O_N2B, lane);
@@ -476,7 +501,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 clm_put4(XA, es, lane, xr);
                 st4(RES + es * 256 + 4 * lane, xr);
             } else if constexpr (WIN) {
+                if (DCLM_IDLE_FLAGS) clm_wait_published(FLG + 2, pub2);
                 cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2A{});
+                if (DCLM_IDLE_FLAGS) cl_flag_wait(FLG + 3, e2);
                 cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2B{});
             }
             __syncthreads(); DEN_DBG(0);
