@@ -390,8 +390,8 @@ def train_mode(args, dev, rank, world, backend, dist_on):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU per pass (BASELINE configs[1]: 32)")
     ap.add_argument("--weights", default="fp16", choices=["fp32", "bf16", "fp16"], help="denoiser weight image dtype")
     ap.add_argument("--vae", default="fp16", choices=["fp32", "fp16"], help="VAE MFMA operand type (fp32 = exact parity path)")
