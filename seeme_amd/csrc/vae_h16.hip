@@ -831,6 +831,50 @@ __device__ __forceinline__ void rows_to_h16(unsigned short* Xh, int ldh, int row
 // (row-major K rows / V^T rows made every wave-load touch 16 rows x 64 B; the V^T rows were written two bytes at a time).
 // Value granules of keys in [S, spv) are written as zeros by the tiles that cover them (P = 0 there, but 0 x garbage is not);
 // key rows in [S, 16 NT16) stay unwritten: their score columns are masked by a select.
+#ifndef LAYER_TAIL_STORES_LAST
+#define LAYER_TAIL_STORES_LAST 1
+#endif
+template <int WAVES, int RW>
+__device__ __forceinline__ void tail_store_q(const unsigned short* Oh, int ld, unsigned short* __restrict__ q_out, size_t base, int q0, int S) {
+    constexpr int NT = 64 * WAVES;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < RW / 2; ++it) {
+        const int idx = tid + it * NT, row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
+        if (s < S) *reinterpret_cast<uint4*>(q_out + (base + s) * 256 + c8) = *reinterpret_cast<const uint4*>(Oh + row * ld + c8);
+    }
+}
+template <int WAVES, int RW>
+__device__ __forceinline__ void tail_store_k(const unsigned short* Oh, int ld, uint4* __restrict__ kp_out, int b, int q0, int S, int NT16) {
+    constexpr int NT = 64 * WAVES;
+    const int tid = threadIdx.x;
+    uint4* kb_out = kp_out + ((size_t)b * NT16 + (q0 >> 4)) * 512;
+#pragma unroll
+    for (int it = 0; it < RW / 2; ++it) {
+        const int idx = tid + it * NT, r = idx & 15, kq = (idx >> 4) & 3, kb = (idx >> 6) & 7, half = idx >> 9, row = half * 16 + r;
+        if (q0 + row < S) kb_out[(half * 8 + kb) * 64 + kq * 16 + r] = *reinterpret_cast<const uint4*>(Oh + row * ld + kb * 32 + kq * 8);
+    }
+}
+template <int WAVES, int RW>
+__device__ __forceinline__ void tail_store_v(const unsigned short* Oh, int ld, uint4* __restrict__ vp_out, int b, int q0, int S, int KB) {
+    constexpr int NT = 64 * WAVES;
+    const int tid = threadIdx.x;
+    uint4* vb_out = vp_out + (size_t)b * 16 * KB * 64;
+#pragma unroll
+    for (int it = 0; it < RW / 2; ++it) {
+        const int idx = tid + it * NT, r = idx & 15, g = (idx >> 4) & 3, nt = (idx >> 6) & 15, kh = idx >> 10;   // kh: 32-key block inside the tile
+        const int row0 = 32 * kh + 8 * g, kb = (q0 >> 5) + kh;
+        const unsigned short* src = Oh + row0 * ld + nt * 16 + r;
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int s0 = q0 + row0 + 2 * j;
+            const unsigned lo = s0 < S ? src[(2 * j) * ld] : 0u, hi = s0 + 1 < S ? src[(2 * j + 1) * ld] : 0u;
+            w[j] = lo | (hi << 16);
+        }
+        if (kb < KB) vb_out[((size_t)nt * KB + kb) * 64 + g * 16 + r] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
 template <int WAVES, int RW, int PF>
 __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned short* Oh, const uint4* __restrict__ qkv_w,
                                               const float* __restrict__ qkv_b, unsigned short* __restrict__ q_out,
@@ -841,6 +885,11 @@ __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned
     const int ldq = 256 + HPAD;
     const size_t base = (size_t)b * S;
     const int NT16 = (S + 15) >> 4, KB = spv >> 5;
+    // All three products first, every global store last: vmcnt is one in-order counter for loads and stores, so a part's B-fragment re-fills
+    // queued behind the previous part's stores waited for their write acknowledgements (round 2 measured 14-22 k cycles for this tail against
+    // 2.7 k for the out_proj of the same shape).  q and K wait in the two halves of the output region (the second without row padding: together
+    // they are exactly the fp32 tile's 32 x 264 x 4 bytes), V in its accumulators.
+#if !LAYER_TAIL_STORES_LAST
     for (int y = 0; y < 3; ++y) {
         f32x4 acc[MTL][NTL];
         acc_zero(acc);
@@ -850,37 +899,44 @@ __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned
         __syncthreads();                    // the previous part's stores have read the output tile
         acc_store_h16<MTL, NTL>(acc, Oh, ldq, wave * CW, bias, SEEME_ACT_NONE);
         __syncthreads();
-        if (y == 0) {
-#pragma unroll
-            for (int it = 0; it < RW / 2; ++it) {
-                const int idx = tid + it * NT, row = idx >> 5, c8 = (idx & 31) * 8, s = q0 + row;
-                if (s < S) *reinterpret_cast<uint4*>(q_out + (base + s) * 256 + c8) = *reinterpret_cast<const uint4*>(Oh + row * ldq + c8);
-            }
-        } else if (y == 1) {
-            uint4* kb_out = kp_out + ((size_t)b * NT16 + (q0 >> 4)) * 512;
-#pragma unroll
-            for (int it = 0; it < RW / 2; ++it) {
-                const int idx = tid + it * NT, r = idx & 15, kq = (idx >> 4) & 3, kb = (idx >> 6) & 7, half = idx >> 9, row = half * 16 + r;
-                if (q0 + row < S) kb_out[(half * 8 + kb) * 64 + kq * 16 + r] = *reinterpret_cast<const uint4*>(Oh + row * ldq + kb * 32 + kq * 8);
-            }
-        } else {
-            uint4* vb_out = vp_out + (size_t)b * 16 * KB * 64;
-#pragma unroll
-            for (int it = 0; it < RW / 2; ++it) {
-                const int idx = tid + it * NT, r = idx & 15, g = (idx >> 4) & 3, nt = (idx >> 6) & 15, kh = idx >> 10;   // kh: 32-key block inside the tile
-                const int row0 = 32 * kh + 8 * g, kb = (q0 >> 5) + kh;
-                const unsigned short* src = Oh + row0 * ldq + nt * 16 + r;
-                unsigned w[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int s0 = q0 + row0 + 2 * j;
-                    const unsigned lo = s0 < S ? src[(2 * j) * ldq] : 0u, hi = s0 + 1 < S ? src[(2 * j + 1) * ldq] : 0u;
-                    w[j] = lo | (hi << 16);
-                }
-                if (kb < KB) vb_out[((size_t)nt * KB + kb) * 64 + g * 16 + r] = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-        }
+        if (y == 0) tail_store_q<WAVES, RW>(Oh, ldq, q_out, base, q0, S);
+        else if (y == 1) tail_store_k<WAVES, RW>(Oh, ldq, kp_out, b, q0, S, NT16);
+        else tail_store_v<WAVES, RW>(Oh, ldq, vp_out, b, q0, S, KB);
     }
+#else
+    constexpr int ldk = 256;                                   // K's staging rows: unpadded (see above)
+    unsigned short* const OhK = Oh + ROWS * ldq;
+    {
+        f32x4 acc[MTL][NTL];
+        acc_zero(acc);
+        const BiasRegs<NTL> bias = bias_load<NTL>(qkv_b, 0 * 256 + wave * CW, 768);
+        gemm_packed<MTL, NTL, PF>(Xh, ldq, qkv_w, 8, 0 * 16 + wave * NTL, 48, 8, acc, ring_t);
+        prime_packed(ring_t, qkv_w, 8, 1 * 16 + wave * NTL, 48, 8);
+        __syncthreads();                    // the earlier phases have read the output region
+        acc_store_h16<MTL, NTL>(acc, Oh, ldq, wave * CW, bias, SEEME_ACT_NONE);
+    }
+    {
+        f32x4 acc[MTL][NTL];
+        acc_zero(acc);
+        const BiasRegs<NTL> bias = bias_load<NTL>(qkv_b, 1 * 256 + wave * CW, 768);
+        gemm_packed<MTL, NTL, PF>(Xh, ldq, qkv_w, 8, 1 * 16 + wave * NTL, 48, 8, acc, ring_t);
+        prime_packed(ring_t, qkv_w, 8, 2 * 16 + wave * NTL, 48, 8);
+        acc_store_h16<MTL, NTL>(acc, OhK, ldk, wave * CW, bias, SEEME_ACT_NONE);
+    }
+    {
+        f32x4 acc[MTL][NTL];
+        acc_zero(acc);
+        const BiasRegs<NTL> bias = bias_load<NTL>(qkv_b, 2 * 256 + wave * CW, 768);
+        gemm_packed<MTL, NTL, PF>(Xh, ldq, qkv_w, 8, 2 * 16 + wave * NTL, 48, 8, acc, ring_t);
+        __syncthreads();                    // q and K tiles complete
+        tail_store_q<WAVES, RW>(Oh, ldq, q_out, base, q0, S);
+        tail_store_k<WAVES, RW>(OhK, ldk, kp_out, b, q0, S, NT16);
+        __syncthreads();                    // ... and read
+        acc_store_h16<MTL, NTL>(acc, Oh, ldq, wave * CW, bias, SEEME_ACT_NONE);
+        __syncthreads();
+        tail_store_v<WAVES, RW>(Oh, ldq, vp_out, b, q0, S, KB);
+    }
+#endif
 }
 
 // debug stamps of a layer that has the next layer's QKV as its tail (the last launch of those in a pass is what is read back)
