@@ -10,9 +10,11 @@ from test_gpu_parity import make_den, _sched
 
 dev = torch.device("cuda:0")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+NTOK = 2 if os.environ.get("N2") else 1          # N2=1: two condition tokens (scene + interactee)
+CONDS = ("text", "scene", "interactee") if NTOK == 2 else ("text", "interactee")
 rng = np.random.default_rng(2026)
-dens = [make_den(dev, weight_dtype="fp16"), make_den(dev, weight_dtype="fp16")]
-ref = make_den(dev, weight_dtype="fp16")
+dens = [make_den(dev, cond=CONDS, weight_dtype="fp16"), make_den(dev, cond=CONDS, weight_dtype="fp16")]
+ref = make_den(dev, cond=CONDS, weight_dtype="fp16")
 ref.cluster_ms = False
 bad = 0
 t0 = time.time()
@@ -22,10 +24,10 @@ for it in range(n_cases):
     kind = "ddpm" if rng.random() < 0.4 else "ddim"
     sch = _sched(kind); sch.set_timesteps(1000 if kind == "ddpm" else 50); sch.timesteps = sch.timesteps[:steps]
     g = torch.Generator(device="cpu").manual_seed(1000 + it)
-    lat = torch.randn(B, 1, 256, generator=g).to(dev); cond = torch.randn(B, 1, 256, generator=g).to(dev)
+    lat = torch.randn(B, 1, 256, generator=g).to(dev); cond = torch.randn(B, NTOK, 256, generator=g).to(dev)
     noise = torch.randn(steps, B, 256, generator=g).to(dev) if kind == "ddpm" else None
     den = dens[it % 2]
-    Cc, spc = den._cluster_plan(B, 1, False, False)
+    Cc, spc = den._cluster_plan(B, NTOK, False, False)
     z = den.sample_loop(lat, cond, sch, step_noise=noise)
     torch.cuda.synchronize()
     st = den.cluster_status()

@@ -10,14 +10,17 @@ sch = _sched(); sch.set_timesteps(50)
 torch.manual_seed(3)
 for B in [int(x) for x in (sys.argv[1:] or ["32", "64", "128"])]:
     lat = torch.randn(B, 1, 256, device=dev); cond = torch.randn(B, 2, 256, device=dev)
-    for cl in ("auto", 0):
-        den.cluster = cl
+    outs = {}
+    for cl in (0, "auto_no_ms", "auto"):
+        den.cluster = "auto" if cl == "auto_no_ms" else cl
+        den.cluster_ms = cl != "auto_no_ms"
         for _ in range(2):
             den.sample_loop(lat, cond, sch)
         torch.cuda.synchronize()
         ts = []
         for _ in range(10):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            den.sample_loop(lat, cond, sch, events=ev); torch.cuda.synchronize(); ts.append(ev[0].elapsed_time(ev[1]))
-        print(json.dumps({"N": 2, "B": B, "cluster": cl, "plan": den._cluster_plan(B, 2, False, False) if cl == "auto" else [0, 1],
-                          "ms": round(float(np.median(ts)), 4)}), flush=True)
+            outs[cl] = den.sample_loop(lat, cond, sch, events=ev); torch.cuda.synchronize(); ts.append(ev[0].elapsed_time(ev[1]))
+        print(json.dumps({"N": 2, "B": B, "cluster": cl, "plan": den._cluster_plan(B, 2, False, False) if cl != 0 else [0, 1],
+                          "ms": round(float(np.median(ts)), 4), "status": den.cluster_status(),
+                          "vs_one_cu": float((outs[cl] - outs[0]).abs().max() / outs[0].abs().max()) if 0 in outs else None}), flush=True)

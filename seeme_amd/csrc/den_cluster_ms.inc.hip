@@ -12,8 +12,8 @@
 // seven waves idle), and every sample has its own granule block and its own two exchanges per layer.
 //   64 < B <= 512: C = 4, 64 clusters x ceil(B / 64) samples   (host policy, seeme_amd/mld_denoiser.py::_cluster_plan; C = 8 is built too and
 //   measures slower: a CU's exchange volume grows with C x samples; up to B = 64 the windowed one-sample kernel on 4 CUs is faster)
-// fp16 weight image (the bench default; two A rows per sample), one condition token (tabulated ca term), one head, no CFG, one
-// timestep row per step: everything else stays on k_den_sample / k_den_cluster.  The weight image, the unit program and the exchange
+// fp16 weight image (the bench default; two A rows per sample), one condition token (tabulated ca term) or two (template Q: query / proj_out
+// stages and a third exchange per sample), one head, no CFG, one timestep row per step: everything else stays on k_den_sample / k_den_cluster.  The weight image, the unit program and the exchange
 // protocol are k_den_cluster's (inline load schedule), results are bit-identical to it; LDS differs: the A-operand buffers hold 16 rows,
 // and the per-layer vector operands are kept in a COMPACT block (only the slices this CU reads: 2 944 floats instead of 6 272 at C = 4)
 // with the samples' K slices behind it; a sample's V' row and its tabulated ca term are read from global memory by its epilogue wave
@@ -46,12 +46,15 @@
 //   W1A after the X1 publish (stage B's units), W1B behind the X1 sweep (stage C's), W2A after the X2 publish (D, E), W2B behind its sweep (F),
 //   W3 in the ffn epilogue (next layer's A, x half), AF after stage F (next layer's A, skip half).  Ring slot of unit U = U % 4: a unit goes
 //   out only after unit U - 4 was consumed (C = 4: A 0 1 | AS 2 3 | B 4 5 | C 6 7 | D 8 | E 9 | F 10 11;  C = 8: A 0 | AS 1 | B 2 | C 3 | D 4 | E 5 | F 6 7).
-template <int C> struct ClmSched;
-template <> struct ClmSched<4> { typedef ClSeq<4, 5> W1A; typedef ClSeq<6, 7> W1B; typedef ClSeq<8, 9> W2A; typedef ClSeq<10, 11> W2B; typedef ClSeq<12, 13> W3; typedef ClSeq<14, 15> AF; };
-template <> struct ClmSched<8> { typedef ClSeq<2, 3> W1A; typedef ClSeq<4> W1B; typedef ClSeq<5> W2A; typedef ClSeq<6> W2B; typedef ClSeq<7> W3; typedef ClSeq<8, 9> AF; };
+// Two condition tokens (Q): the unit tables and windows of ClSched<C, true, true> (den_cluster.inc.hip), WXA / WXB around the third exchange.
+template <int C, bool Q> struct ClmSched;
+template <> struct ClmSched<4, false> { static constexpr int PRO = 4; typedef ClSeq<4, 5> W1A; typedef ClSeq<6, 7> W1B; typedef ClSeq<8, 9> W2A; typedef ClSeq<10, 11> W2B; typedef ClSeq<> WXA, WXB; typedef ClSeq<12, 13> W3; typedef ClSeq<14, 15> AF; };
+template <> struct ClmSched<8, false> { static constexpr int PRO = 2; typedef ClSeq<2, 3> W1A; typedef ClSeq<4> W1B; typedef ClSeq<5> W2A; typedef ClSeq<6> W2B; typedef ClSeq<> WXA, WXB; typedef ClSeq<7> W3; typedef ClSeq<8, 9> AF; };
+template <> struct ClmSched<4, true> { static constexpr int PRO = 4; typedef ClSeq<4, 5> W1A; typedef ClSeq<6, 7> W1B; typedef ClSeq<8, 9> W2A; typedef ClSeq<10> W2B; typedef ClSeq<11> WXA; typedef ClSeq<12> WXB; typedef ClSeq<13, 14> W3; typedef ClSeq<16, 17, 18, 19> AF; };
+template <> struct ClmSched<8, true> { static constexpr int PRO = 2; typedef ClSeq<2, 3> W1A; typedef ClSeq<4> W1B; typedef ClSeq<5> W2A; typedef ClSeq<6> W2B; typedef ClSeq<7> WXA; typedef ClSeq<8> WXB; typedef ClSeq<9, 10> W3; typedef ClSeq<12, 13> AF; };
 
-template <int C> struct ClM {
-    typedef ClG<C, false> G;
+template <int C, bool Q = false> struct ClM {
+    typedef ClG<C, Q> G;
     static constexpr int MS = 8;                         // samples per cluster
     static constexpr int XKB = 1024;                     // bytes per k-block of an A-operand buffer: [k-group 4][row 16][8 halves]
     static constexpr int XBUF = 256 / 32 * XKB / 4;      // floats of a 256-k operand buffer (8 KiB)
@@ -62,13 +65,20 @@ template <int C> struct ClM {
                          O_N2W = O_L2B + 256, O_N2B = O_N2W + 256, O_F1B = O_N2B + 256, O_F2B = O_F1B + FF_D, O_FSNW = O_F2B + 256,
                          O_FSNB = O_FSNW + 256, O_FOB = O_FSNB + 256, O_L1B = O_FOB + 256,
                          O_TK = O_L1B + G::NB /* time token K | V' | ffn AdaLN scale | shift */, O_TV = O_TK + 256, O_TSC = O_TV + 256, O_TSH = O_TSC + 256,
-                         O_SMP = O_TSH + 256;            // per sample [MS][S]: this CU's dims of the condition token's K (its V' row and the
-                                                         // tabulated ca term are read from global memory by the sample's epilogue wave, under its exchanges)
-    static constexpr int STG = O_SMP + MS * G::S;
+                         // (Q) ca AdaLN scale | shift, ca_block.norm weight | bias, proj_out.norm weight | bias, proj_out bias, this CU's slice of the query bias
+                         O_CSC = O_TSH + 256, O_CSH = O_CSC + (Q ? 256 : 0), O_CNW = O_CSH + (Q ? 256 : 0), O_CNB = O_CNW + (Q ? 256 : 0),
+                         O_CSNW = O_CNB + (Q ? 256 : 0), O_CSNB = O_CSNW + (Q ? 256 : 0), O_CAOB = O_CSNB + (Q ? 256 : 0), O_CAQB = O_CAOB + (Q ? 256 : 0),
+                         O_SMP = O_CAQB + (Q ? G::S : 0);   // per sample [MS][SMPF]: this CU's dims of the condition token's K (Q: sa K of token 0 | token 1 |
+                                                            // ca key of token 0 | token 1); V' / ca value rows and the tabulated ca term are read from global
+                                                            // memory by the sample's epilogue wave, under its exchanges
+    static constexpr int SMPF = (Q ? 4 : 1) * G::S;
+    static constexpr int STG = O_SMP + MS * SMPF;
     static constexpr int NL1 = G::NB > 256 ? G::NB / 256 : 1;
-    static constexpr int NKP = MS * G::S / 256;          // pieces of the samples' K slices
-    static constexpr int NPIECE = 14 + NL1 + 4 + NKP;    // <= 24: one piece per wave in each of the phases B, D, F (as k_den_cluster)
-    static_assert(NPIECE <= 24 && MS * G::S % 256 == 0, "staging pieces");
+    static constexpr int NSH = 14 + NL1 + 4 + (Q ? 8 : 0);   // pieces shared by the samples
+    static constexpr int NKP = MS * SMPF / 256;          // pieces of the samples' K slices
+    static constexpr int NPIECE = NSH + NKP;             // one piece per wave in each of the phases B, D, F (Q: B, C, H, D, F), as k_den_cluster
+    static constexpr int NPH = Q ? 5 : 3;
+    static_assert(NPIECE <= 8 * NPH && MS * SMPF % 256 == 0, "staging pieces");
     static constexpr int LDS_FLOATS = 768 + MS * 256 + 2 * STG + 2 * XBUF + XHBUF + 2 * XBUF + 2 * MS * G::S + 2 * MS * 256 + 4;
 };
 
@@ -116,12 +126,12 @@ __device__ __forceinline__ void clm_published(int* f, int lane, int target) {
 
 // one piece (<= 1 KiB) of the NEXT layer's operands per wave and phase k = 0 .. 5: requested at the top of the phase, stored to the other
 // half of the staging buffer at its end (k_den_cluster's ClStage, with the compact destination layout and MS samples' rows)
-template <int C>
+template <int C, bool Q>
 struct ClmStage {
     float4 r; int dst, n4;
     __device__ __forceinline__ void load(int k, int wave, int lane, const float* __restrict__ vpg, const DenLayerOff* __restrict__ L,
                                          const float* __restrict__ tt_row, int l, const SeemeSampleArgs& A, int b0, int nact, int c) {
-        typedef ClM<C> M; typedef ClG<C, false> G;
+        typedef ClM<C, Q> M; typedef ClG<C, Q> G;
         const float* vb = vpg + L->skip_b;
         const int i = wave + 8 * k;
         const float* src = vb; int d = 0, n = 0;
@@ -142,11 +152,28 @@ struct ClmStage {
             src = j < 2 ? tt_row + l * 512 + j * 256 : tt_row + 2560 + l * 1024 + 512 + (j - 2) * 256;
             d = M::O_TK + j * 256; n = 64;
         }
-        else if (i < M::NPIECE) {                          // the samples' K slices: 256 floats per piece = 256 / S samples
-            const int e = (i - 18 - M::NL1) * 256 + 4 * lane, s = e / G::S, off = e - s * G::S;
+        else if (Q && i < M::NSH) {
+            const int j = i - 18 - M::NL1;                 // ca AdaLN scale | shift; ca_block.norm, proj_out.norm, proj_out bias; query bias slice
+            if (j < 2) { src = tt_row + 2560 + l * 1024 + j * 256; d = M::O_CSC + j * 256; n = 64; }
+            else if (j < 7) {
+                const int64_t f = j == 2 ? L->cnw : j == 3 ? L->cnb : j == 4 ? L->csnw : j == 5 ? L->csnb : L->cao_b;
+                src = vpg + f; d = M::O_CNW + (j - 2) * 256; n = 64;
+            }
+            else { src = vpg + L->caq_b + c * G::S; d = M::O_CAQB; n = G::S / 4; }
+        }
+        else if (i < M::NPIECE) {                          // the samples' K slices: 256 floats per piece, each lane from its own sample's row --
+            // through a buffer over the condition tables with a 32-bit lane offset (a per-lane 64-bit address kept across the layer loop is
+            // spilled, and its reload drains the vector-memory queue)
+            int ll = lane;
+            asm volatile("" : "+v"(ll));                 // (recomputed at every call: hoisted out of the layer loop the offset is spilled as well)
+            const int e = (i - M::NSH) * 256 + 4 * ll, s = e / M::SMPF, r_ = e - s * M::SMPF, q = r_ / G::S, off = r_ - q * G::S;
             const int bs = b0 + (s < nact ? s : 0);        // (slots beyond the batch read sample b0: never used)
-            src = A.ctab + (size_t)bs * SEEME_CROW + l * 512 + c * G::S + off - 4 * lane;      // (per-lane source: the common "+ 4 lane" below)
-            d = M::O_SMP + (i - 18 - M::NL1) * 256; n = 64;
+            const int N = Q ? 2 : 1, t = q & 1;            // q: sa K of token 0 [| token 1 | ca key of token 0 | token 1]
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.ctab), 0, A.B * N * SEEME_CROW * 4, 0x00020000);
+            const unsigned vo = (unsigned)(((bs * N + t) * SEEME_CROW + (q < 2 ? 0 : 2560) + c * G::S + off) * 4);
+            dst = M::O_SMP + (i - M::NSH) * 256; n4 = 64;
+            r = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rc, vo, (unsigned)(l * 512 * 4), 0));
+            return;
         }
         dst = d; n4 = n;
         r = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -162,17 +189,19 @@ struct ClmStage {
     }
 };
 
-template <int C>
+template <int C, bool Q>
 __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef WF16 WT;
-    typedef ClW<WT> W; typedef ClG<C, false> G; typedef ClM<C> M;
-    constexpr bool Q = false;
+    typedef ClW<WT> W; typedef ClG<C, Q> G; typedef ClM<C, Q> M;
     constexpr int MS = M::MS;
+    constexpr int N = Q ? 2 : 1;                 // condition tokens
+    constexpr int NT = N + 2;                    // score slots: self, condition token(s), time
     constexpr int A_DEF0 = cl_clamp(2 * G::TA - W::RU, 0, 2 * G::TA);
     constexpr bool WIN = DCLM_WIN != 0;
+    static_assert(WIN || !Q, "two condition tokens: windowed schedule only");
     constexpr int A_INL0 = WIN ? 0 : cl_clamp(A_DEF0, 0, G::TA), A_INL1 = WIN ? 0 : cl_clamp(A_DEF0 - G::TA, 0, G::TA), C_INL = WIN ? 0 : cl_clamp(G::TB - W::RU, 0, G::TB);
-    typedef ClmSched<C> SCH;
+    typedef ClmSched<C, Q> SCH;
     const SeemeSampleArgs& A = ka.s;
     const DenLayout* __restrict__ lay = &ka.lay;
     const float* __restrict__ vp = ka.vp;
@@ -211,9 +240,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
     const __amdgpu_buffer_rsrc_t xr_ = __builtin_amdgcn_make_buffer_rsrc(xg, 0, G::G_TOTAL * 8, 0x00020000);
     // this wave's sample: its condition-table row and its block of the tabulated ca term, as buffers (scalar base + lane offset: a per-lane
     // 64-bit address kept across the layer loop is spilled, and its reload drains the vector-memory queue)
-    const __amdgpu_buffer_rsrc_t rs_ct = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.ctab + (size_t)bs * SEEME_CROW), 0, SEEME_CROW * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_ca = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.catab + (size_t)bs * ca_R * SEEME_DEN_NL * 256), 0,
-                                                                           ca_R * SEEME_DEN_NL * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ct = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.ctab + (size_t)bs * N * SEEME_CROW), 0, N * SEEME_CROW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ca = __builtin_amdgcn_make_buffer_rsrc(Q ? nullptr : const_cast<float*>(A.catab + (size_t)bs * ca_R * SEEME_DEN_NL * 256), 0,
+                                                                           Q ? 0 : ca_R * SEEME_DEN_NL * 1024, 0x00020000);   // (Q: no tabulated ca term)
     const unsigned voff = (unsigned)wave * (unsigned)(W::UL * 1024) + (unsigned)lane * 16u;
     const int col = lane & 15;
     const ClX xa = clm_xin(XA, lane), xb = clm_xin(XB, lane), xh = clm_xin(XH, lane);
@@ -231,9 +260,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
     for (int i = tid; i < 192; i += DEN_THREADS)
         st4(CONSTV + 4 * i, i < 64 ? ld4(vp + lay->pe0 + 4 * i) : (i < 128 ? ld4(vp + lay->fnw + 4 * (i - 64)) : ld4(vp + lay->fnb + 4 * (i - 128))));
     {
-        ClmStage<C> p;
+        ClmStage<C, Q> p;
 #pragma unroll 1
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < M::NPH; ++k) {
             p.load(k, wave, lane, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b0, nact, c);
             p.store(lane, STG);
         }
@@ -271,7 +300,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
         const unsigned bb = (unsigned)((0 * C + c) * G::NU) * W::UNIT_BYTES;
         cl_issue<WT, C, Q, 0>(ring, wave, voff, wg, bb, bb, false, false);
         cl_issue<WT, C, Q, 1>(ring, wave, voff, wg, bb, bb, false, false);
-        if constexpr (!WIN || C == 4) {      // (C = 8, windowed: units 2, 3 go out in the first X1 window)
+        if constexpr (!WIN || SCH::PRO == 4) {      // (PRO = 2: units 2, 3 go out in the first X1 window)
             cl_issue<WT, C, Q, 2>(ring, wave, voff, wg, bb, bb, false, false);
             cl_issue<WT, C, Q, 3>(ring, wave, voff, wg, bb, bb, false, false);
         }
@@ -294,11 +323,12 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
             const unsigned bc = (unsigned)((l * C + c) * G::NU) * W::UNIT_BYTES, bn = (unsigned)((ln * C + c) * G::NU) * W::UNIT_BYTES;
             const float* VP = STG + cur * M::STG;
             float* const STGN = STG + (cur ^ 1) * M::STG;
-            const float* SMP = VP + M::O_SMP + es * G::S;        // this wave's sample: the condition token's K over this CU's dims
+            const float* SMP = VP + M::O_SMP + es * M::SMPF;     // this wave's sample: the condition tokens' K (and ca keys) over this CU's dims
             const bool ywave = wave >= 6;
-            const unsigned e1 = 1u + 2u * (unsigned)(step * SEEME_DEN_NL + l), e2 = e1 + 1u;
-            const int pub1 = nact * (int)e1, pub2 = nact * (int)e2;   // the LDS count of published samples after X1 / X2 of this layer (FLG[2])
-            ClmStage<C> nxt;
+            const unsigned e1 = 1u + (unsigned)G::EPL * (unsigned)(step * SEEME_DEN_NL + l), e2 = e1 + 1u, e3 = e1 + 2u;
+            const int pub1 = nact * (int)e1, pub2 = nact * (int)e2, pub3 = nact * (int)e3;   // the LDS count of published samples after X1 / X2 / X3 of this layer (FLG[2])
+            (void)e3; (void)pub3;
+            ClmStage<C, Q> nxt;
             const float* const tt_next = A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW;
 
             // ================= A: in_proj' (+ folded skip linear), column-split by dims =================
@@ -335,27 +365,33 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
             __syncthreads(); DEN_DBG(0);
             if (epi) {
                 const unsigned epoch = e1;
-                float ps[3] = {0.f, 0.f, 0.f};                   // score slots: self, condition, time (mdiff_transformer.py:295)
+                float ps[NT];                                    // score slots: self, condition token(s), time (mdiff_transformer.py:295)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) ps[j] = 0.f;
 #pragma unroll
                 for (int dd = 0; dd < G::S; dd += 64) {
                     const int d = dd + lane;
                     if (d < G::S) {
                         const float q = QS[es * G::S + d];
                         ps[0] = fmaf(q, KS[es * G::S + d], ps[0]);
-                        ps[1] = fmaf(q, SMP[d], ps[1]);
-                        ps[2] = fmaf(q, VP[M::O_TK + c * G::S + d], ps[2]);
+#pragma unroll
+                        for (int n = 0; n < N; ++n) ps[1 + n] = fmaf(q, SMP[n * G::S + d], ps[1 + n]);
+                        ps[NT - 1] = fmaf(q, VP[M::O_TK + c * G::S + d], ps[NT - 1]);
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 3; ++j) ps[j] = wave_sum(ps[j]) * sa_scale;
+                for (int j = 0; j < NT; ++j) ps[j] = wave_sum(ps[j]) * sa_scale;
                 {
                     float pv = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) pv = lane == j ? ps[j] : pv;
+                    for (int j = 0; j < NT; ++j) pv = lane == j ? ps[j] : pv;
                     if (lane < G::SC) cl_store_granule(xg + G::G_X1 + c * G::X1_G + 2 * G::S + lane, epoch, pv, local);
                 }
-                // the condition token's V' row of this sample: requested here, lands while the exchange is waited for
-                const float4 cvp = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_ct, (unsigned)lane * 16u, (unsigned)((l * 512 + 256) * 4), 0));
+                // the condition tokens' V' rows of this sample: requested here, they land while the exchange is waited for
+                float4 cvp[N];
+#pragma unroll
+                for (int n = 0; n < N; ++n)
+                    cvp[n] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_ct, (unsigned)lane * 16u, (unsigned)((n * SEEME_CROW + l * 512 + 256) * 4), 0));
                 if constexpr (WIN) { __builtin_amdgcn_sched_barrier(0); clm_published(FLG + 2, lane, pub1); cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1A{}); }
                 // ---- X1: gather v' (and y), all-reduce the scores
                 const int pub = (4 * lane) / G::S, off = (4 * lane) % G::S;
@@ -395,23 +431,26 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 }
                 if constexpr (WIN) { cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W1B{}); if (DCLM_IDLE_FLAGS && wave == 0 && lane == 0) cl_flag_set(FLG + 3, e1); }
                 DEN_DBG(0);
-                float sc[3];
+                float sc[NT];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < NT; ++j) {
                     sc[j] = __uint_as_float((j & 1) ? gs[j >> 1].z : gs[j >> 1].x);
                     if (C >= 2) sc[j] += dpp_f(sc[j], 0);
                     if (C >= 4) sc[j] += dpp_f(sc[j], 1);
                     if (C >= 8) sc[j] += dpp_f(sc[j], 2);
                 }
-                const float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+                float mx = sc[0];
+#pragma unroll
+                for (int j = 1; j < NT; ++j) mx = fmaxf(mx, sc[j]);
                 float esum = 0.f;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) { sc[j] = fast_exp(sc[j] - mx); esum += sc[j]; }
+                for (int j = 0; j < NT; ++j) { sc[j] = fast_exp(sc[j] - mx); esum += sc[j]; }
                 const float inv = fast_rcp(esum);
                 const float4 vv = make_float4(__uint_as_float(gv0.x), __uint_as_float(gv0.z), __uint_as_float(gv1.x), __uint_as_float(gv1.z));
                 float4 att = f4_scale(vv, sc[0] * inv);
-                att = f4_fma(sc[1] * inv, cvp, att);
-                att = f4_fma(sc[2] * inv, ld4(VP + M::O_TV + 4 * lane), att);
+#pragma unroll
+                for (int n = 0; n < N; ++n) att = f4_fma(sc[1 + n] * inv, cvp[n], att);
+                att = f4_fma(sc[NT - 1] * inv, ld4(VP + M::O_TV + 4 * lane), att);
                 if (skip) xr = make_float4(__uint_as_float(gy0.x), __uint_as_float(gy0.z), __uint_as_float(gy1.x), __uint_as_float(gy1.z));
                 xr = wave_ln(f4_add(xr, att), VP + M::O_N1W, VP + M::O_N1B, lane);        // the "values" carry out_proj: residual + norm1
                 clm_put4(XB, es, lane, xr);
@@ -444,6 +483,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
             __syncthreads(); DEN_DBG(0);
 
             // ================= C: linear2, row-split -> X2 =================
+            if constexpr (Q) nxt.load(1, wave, lane, vp, Ln, tt_next, ln, A, b0, nact, c);
             {
                 f32x4 acc[2];
                 cl_zero<2>(acc);
@@ -456,10 +496,12 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                         if (g2 + j < nact) cl_store_granule(xg0 + (size_t)(g2 + j) * G::G_TOTAL + G::G_X2 + c * 256 + n, e2, clm_out(acc[tt], j), local);
                 }
             }
+            if constexpr (Q) nxt.store(lane, STGN);
             if (epi) {
                 const unsigned epoch = e2;
                 // the tabulated ca_block term of this (sample, step, layer): requested here, lands while the exchange is waited for
-                const float4 cadd = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_ca, (unsigned)lane * 16u, (unsigned)((step * SEEME_DEN_NL + l) * 1024), 0));
+                float4 cadd = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (!Q) cadd = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_ca, (unsigned)lane * 16u, (unsigned)((step * SEEME_DEN_NL + l) * 1024), 0));
                 if constexpr (WIN) { __builtin_amdgcn_sched_barrier(0); clm_published(FLG + 2, lane, pub2); cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W2A{}); }
                 float4 sum;
                 unsigned spins = 0;
@@ -497,8 +539,12 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 DEN_DBG(0);
                 // + bias, residual, norm2, + the tabulated ca_block term (one condition token: seeme_denoiser_ca_tables)
                 xr = wave_ln(f4_add(xr, f4_add(sum, ld4(VP + M::O_L2B + 4 * lane))), VP + M::O_N2W, VP + M::O_N2B, lane);
-                xr = f4_add(xr, cadd);
-                clm_put4(XA, es, lane, xr);
+                if constexpr (!Q) {
+                    xr = f4_add(xr, cadd);
+                    clm_put4(XA, es, lane, xr);
+                } else {
+                    clm_put4(XB, es, lane, wave_ln(xr, VP + M::O_CNW, VP + M::O_CNB, lane));   // ca_block.norm -> input of the query (mdiff_transformer.py:229)
+                }
                 st4(RES + es * 256 + 4 * lane, xr);
             } else if constexpr (WIN) {
                 if (DCLM_IDLE_FLAGS) clm_wait_published(FLG + 2, pub2);
@@ -508,8 +554,137 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
             }
             __syncthreads(); DEN_DBG(0);
 
+            if constexpr (Q) {
+                // ================= G: ca_block.query, column-split by dims (waves < S / 16 own one tile each) -> X3 =================
+                {
+                    f32x4 acc[1];
+                    cl_zero<1>(acc);
+                    const bool act = wave < G::S / 16;
+                    cl_units<WT, C, Q, G::U_G, 1, 1, 0, 0, 0>(ring, xb, acc, act, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 1>{});
+                    if (act) {
+                        const float bq = VP[M::O_CAQB + wave * 16 + col];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            if (g2 + j < nact) QS[(g2 + j) * G::S + wave * 16 + col] = clm_out(acc[0], j) + bq;
+                    }
+                }
+                __syncthreads(); DEN_DBG(0);
+                if (epi) {
+                    // split softmax of the query over the cluster (k_den_cluster, stage G / X3): this CU holds S dims of sample es
+                    const unsigned epoch = e3;
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int dd = 0; dd < G::S; dd += 64) { const int d = dd + lane; if (d < G::S) m = fmaxf(m, QS[es * G::S + d]); }
+                    m = wave_max(m);
+                    float lsum = 0.f, tn[N];
+#pragma unroll
+                    for (int n = 0; n < N; ++n) tn[n] = 0.f;
+#pragma unroll
+                    for (int dd = 0; dd < G::S; dd += 64) {
+                        const int d = dd + lane;
+                        if (d < G::S) {
+                            const float e = fast_exp(QS[es * G::S + d] - m);
+                            lsum += e;
+                            float kr[N], kmx = -INFINITY, ks = 0.f;
+#pragma unroll
+                            for (int n = 0; n < N; ++n) { kr[n] = SMP[(2 + n) * G::S + d]; kmx = fmaxf(kmx, kr[n]); }
+#pragma unroll
+                            for (int n = 0; n < N; ++n) { kr[n] = fast_exp(kr[n] - kmx); ks += kr[n]; }
+                            const float rks = fast_rcp(ks);
+#pragma unroll
+                            for (int n = 0; n < N; ++n) tn[n] = fmaf(e, kr[n] * rks, tn[n]);
+                        }
+                    }
+                    lsum = wave_sum(lsum);
+#pragma unroll
+                    for (int n = 0; n < N; ++n) tn[n] = wave_sum(tn[n]);
+                    {
+                        float pv = lane == 0 ? m : (lane == 1 ? lsum : 0.f);
+#pragma unroll
+                        for (int n = 0; n < N; ++n) pv = lane == 2 + n ? tn[n] : pv;
+                        if (lane < 8) cl_store_granule(xg + G::G_X3 + c * 8 + lane, epoch, pv, local);
+                    }
+                    // the condition tokens' ca value rows of this sample: requested here, they land while the exchange is waited for
+                    float4 cav[N];
+#pragma unroll
+                    for (int n = 0; n < N; ++n)
+                        cav[n] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_ct, (unsigned)lane * 16u, (unsigned)((n * SEEME_CROW + 2560 + l * 512 + 256) * 4), 0));
+                    __builtin_amdgcn_sched_barrier(0);
+                    clm_published(FLG + 2, lane, pub3);
+                    cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::WXA{});
+                    __builtin_amdgcn_s_sleep(DCLM_POLL_SLEEP);
+                    const unsigned o3 = (unsigned)((G::G_X3 + (lane % C) * 8) * 8);
+                    u32x4 g3[4];
+                    unsigned spins = 0;
+                    for (;;) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) g3[j] = __builtin_amdgcn_raw_buffer_load_b128(xr_, o3 + 16 * j, 0, 16);
+                        unsigned ok = 1u;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ok &= cl_tags_ok(g3[j], epoch);
+                        if (__all(ok != 0u) || dead) break;
+                        if (++spins > DCL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(ka.hdr, 8u); break; }
+                    }
+                    cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::WXB{});
+                    if (DCLM_IDLE_FLAGS && wave == 0 && lane == 0) cl_flag_set(FLG + 3, e3);
+                    DEN_DBG(0);
+                    const float mc = __uint_as_float(g3[0].x), lc = __uint_as_float(g3[0].z);
+                    float Mx = mc;
+                    if (C >= 2) Mx = fmaxf(Mx, dpp_f(Mx, 0));
+                    if (C >= 4) Mx = fmaxf(Mx, dpp_f(Mx, 1));
+                    if (C >= 8) Mx = fmaxf(Mx, dpp_f(Mx, 2));
+                    const float wc = fast_exp(mc - Mx);
+                    float Lw = lc * wc;
+                    if (C >= 2) Lw += dpp_f(Lw, 0);
+                    if (C >= 4) Lw += dpp_f(Lw, 1);
+                    if (C >= 8) Lw += dpp_f(Lw, 2);
+                    const float rL = fast_rcp(Lw);
+                    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int n = 0; n < N; ++n) {
+                        float t = __uint_as_float((n & 1) ? g3[1 + (n >> 1)].z : g3[1 + (n >> 1)].x) * wc;
+                        if (C >= 2) t += dpp_f(t, 0);
+                        if (C >= 4) t += dpp_f(t, 1);
+                        if (C >= 8) t += dpp_f(t, 2);
+                        y = f4_fma(t * rL, cav[n], y);                                              // (q k^T) v  (mdiff_transformer.py:236-237)
+                    }
+                    // StylizationBlock (mdiff_transformer.py:152-163): SiLU(LN(y) (1 + scale) + shift) -> proj_out.out_layers
+                    const float4 hh = f4_adaln(wave_ln(y, VP + M::O_CSNW, VP + M::O_CSNB, lane), ld4(VP + M::O_CSC + 4 * lane), ld4(VP + M::O_CSH + 4 * lane));
+                    clm_put4(XB, es, lane, f4_silu(hh));
+                } else {
+                    if (DCLM_IDLE_FLAGS) clm_wait_published(FLG + 2, pub3);
+                    cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::WXA{});
+                    if (DCLM_IDLE_FLAGS) cl_flag_wait(FLG + 3, e3);
+                    cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::WXB{});
+                }
+                __syncthreads(); DEN_DBG(0);
+                // ================= H: ca_block.proj_out.out_layers + residual (replicated) =================
+                nxt.load(2, wave, lane, vp, Ln, tt_next, ln, A, b0, nact, c);
+                {
+                    f32x4 acc[2];
+                    cl_zero<2>(acc);
+                    cl_units<WT, C, Q, G::U_H, 2, 2, 0, 0, 0>(ring, xb, acc, true, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, 2>{});
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int n = (2 * wave + tt) * 16 + col;
+                        const float bo = VP[M::O_CAOB + n];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int sj = g2 + j;
+                            if (sj < nact) {
+                                const float x3 = RES[sj * 256 + n] + clm_out(acc[tt], j) + bo;
+                                RES[sj * 256 + n] = x3;
+                                clm_put1(XA, sj, n, x3);
+                            }
+                        }
+                    }
+                }
+                nxt.store(lane, STGN);
+                __syncthreads(); DEN_DBG(0);
+            }
+
             // ================= D: ffn.linear1 + GELU (replicated) =================
-            nxt.load(1, wave, lane, vp, Ln, tt_next, ln, A, b0, nact, c);
+            nxt.load(Q ? 3 : 1, wave, lane, vp, Ln, tt_next, ln, A, b0, nact, c);
             if constexpr (!WIN) cl_refills<WT, C, Q, G::U_C + C_INL>(ring, wave, voff, wg, bc, bn, skip, nskip, std::make_integer_sequence<int, G::TB - C_INL>{});       // slots of stage C
             {
                 f32x4 acc[1];
@@ -543,7 +718,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
             }
             __syncthreads(); DEN_DBG(0);
             // ================= F: ffn.proj_out.out_layers + residual (replicated); writes the next layer's input =================
-            nxt.load(2, wave, lane, vp, Ln, tt_next, ln, A, b0, nact, c);
+            nxt.load(Q ? 4 : 2, wave, lane, vp, Ln, tt_next, ln, A, b0, nact, c);
             {
                 f32x4 acc[2];
                 cl_zero<2>(acc);
@@ -614,13 +789,13 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
 // clusters of a launch: ceil(B / spc) rounded up to a multiple of 8 (one per XCD group under either placement)
 static int clm_clusters(int B, int spc) { return ((B + spc - 1) / spc + 7) / 8 * 8; }
 
-extern "C" size_t seeme_den_cluster_ms_xchg_bytes(int B, int C, int spc) {
+extern "C" size_t seeme_den_cluster_ms_xchg_bytes(int B, int C, int spc) {      // (the two-token layout: the larger of the two)
     if (spc < 1 || spc > 8 || (C != 4 && C != 8)) return 0;
-    const size_t per = C == 8 ? ClG<8, false>::G_TOTAL : ClG<4, false>::G_TOTAL;
+    const size_t per = C == 8 ? ClG<8, true>::G_TOTAL : ClG<4, true>::G_TOTAL;
     return DCL_HDR_BYTES + (size_t)clm_clusters(B, spc) * 8 * per * 8;
 }
 
-template <int C>
+template <int C, bool Q>
 static int launch_den_cluster_ms(const ClArgs& ka0, hipStream_t st) {
     ClArgs ka = ka0;
     ka.clusters = clm_clusters(ka.s.B, ka.spc);
@@ -629,11 +804,11 @@ static int launch_den_cluster_ms(const ClArgs& ka0, hipStream_t st) {
     SEEME_HIP(hipGetDevice(&dev));
     SEEME_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (grid > cus || grid > 256) return seeme_fail("denoiser_sample_cluster: clusters x C exceeds one workgroup per CU of this device");
-    const size_t lds = (size_t)ClM<C>::LDS_FLOATS * sizeof(float);
+    const size_t lds = (size_t)ClM<C, Q>::LDS_FLOATS * sizeof(float);
     if (lds > 160 * 1024 || lds <= 80 * 1024) return seeme_fail("denoiser_sample_cluster: LDS footprint must force one workgroup per CU");
-    SEEME_HIP(hipFuncSetAttribute((const void*)k_den_cluster_ms<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_den_cluster_ms<C, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SEEME_HIP(hipMemsetAsync(ka.hdr, 0, seeme_den_cluster_ms_xchg_bytes(ka.s.B, C, ka.spc), st));
-    hipLaunchKernelGGL((k_den_cluster_ms<C>), dim3(grid), dim3(DEN_THREADS), lds, st, ka);
+    hipLaunchKernelGGL((k_den_cluster_ms<C, Q>), dim3(grid), dim3(DEN_THREADS), lds, st, ka);
     return seeme_check_launch("k_den_cluster_ms");
 }
 
@@ -642,9 +817,10 @@ static int den_cluster_ms_dispatch(const SeemeDenoiserWeights* w, const SeemeDen
     if (cl->wdtype != 2) return seeme_fail("denoiser_sample_cluster: several samples per cluster need the fp16 weight image");
     if (cl->C != 4 && cl->C != 8) return seeme_fail("denoiser_sample_cluster: several samples per cluster need C = 4 or 8");
     if (cl->samples > 8) return seeme_fail("denoiser_sample_cluster: at most 8 samples per cluster");
-    if (a->N != 1 || cl->query) return seeme_fail("denoiser_sample_cluster: several samples per cluster need one condition token");
+    if (a->N != 1 && a->N != 2) return seeme_fail("denoiser_sample_cluster: several samples per cluster need one or two condition tokens");
     if (a->trow_per_sample) return seeme_fail("denoiser_sample_cluster: several samples per cluster share the step's table row");
     if (cl->xchg_bytes < seeme_den_cluster_ms_xchg_bytes(a->B, cl->C, cl->samples)) return seeme_fail("denoiser_sample_cluster: exchange buffer too small");
     ka.spc = cl->samples;
-    return cl->C == 8 ? launch_den_cluster_ms<8>(ka, st) : launch_den_cluster_ms<4>(ka, st);
+    if (a->N == 2) return cl->C == 8 ? launch_den_cluster_ms<8, true>(ka, st) : launch_den_cluster_ms<4, true>(ka, st);
+    return cl->C == 8 ? launch_den_cluster_ms<8, false>(ka, st) : launch_den_cluster_ms<4, false>(ka, st);
 }

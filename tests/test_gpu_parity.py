@@ -1022,8 +1022,9 @@ def test_auto_cluster_policy(dev):
     d16 = make_den(dev, weight_dtype="fp16")
     assert [d16._cluster_plan(B, 1, False, False) for B in (32, 33, 64, 65, 128, 129, 256, 257, 512, 513)] == \
         [(8, 1), (4, 1), (4, 1), (4, 2), (4, 2), (4, 3), (4, 4), (4, 5), (4, 8), (0, 1)]
-    # ... not for two condition tokens, CFG pairs, per-sample timesteps, or when switched off
-    assert d16._cluster_plan(128, 2, False, False) == (2, 1) and d16._cluster_plan(128, 1, True, False) == (0, 1)
+    # ... with two condition tokens up to six samples per cluster; not for CFG pairs, per-sample timesteps, or when switched off
+    assert [d16._cluster_plan(B, 2, False, False) for B in (64, 128, 384, 385)] == [(4, 1), (4, 2), (4, 6), (0, 1)]
+    assert d16._cluster_plan(128, 3, False, False) == (0, 1) and d16._cluster_plan(128, 1, True, False) == (0, 1)
     assert d16._cluster_plan(128, 1, False, True) == (2, 1)
     d16.cluster_ms = False
     assert d16._cluster_plan(128, 1, False, False) == (2, 1)
@@ -1061,6 +1062,34 @@ def test_cluster_ms_equals_one_sample_cluster(dev, B, sched):
     ch = 256 // Cc
     ref = torch.cat([den.sample_loop(lat[i:i + ch].contiguous(), cond[i:i + ch].contiguous(), sch,
                                      step_noise=None if noise is None else noise[:, i:i + ch].contiguous()) for i in range(0, B, ch)], 1)
+    torch.cuda.synchronize()
+    assert torch.equal(z, ref), float((z - ref).abs().max())
+    _with_cluster(den, 0)
+    one = den.sample_loop(lat, cond, sch, step_noise=noise)
+    assert rel_err(z.cpu().numpy(), one.cpu().numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("B,sched", [(100, "ddim"), (330, "ddpm")])
+def test_cluster_ms_two_condition_tokens(dev, B, sched):
+    """k_den_cluster_ms with scene + interactee (N = 2, the shipped config_mld_egobody.yaml:114): the ca_block's query / proj_out stages and
+    the third exchange per sample (mdiff_transformer.py:219-239), bit-identical to k_den_cluster<.., 4, Q> on the same samples 64 at a time
+    and within fp16 rounding of the one-CU kernel."""
+    den = make_den(dev, cond=("text", "scene", "interactee"), weight_dtype="fp16")
+    steps = 10
+    sch = _sched(sched)
+    sch.set_timesteps(1000 if sched == "ddpm" else 50)
+    sch.timesteps = sch.timesteps[:steps]
+    torch.manual_seed(B)
+    lat, cond = torch.randn(B, 1, 256, device=dev), torch.randn(B, 2, 256, device=dev)
+    noise = torch.randn(steps, B, 256, device=dev) if sched == "ddpm" else None
+    assert den._cluster_plan(B, 2, False, False) == (4, -(-B // 64))
+    z = den.sample_loop(lat, cond, sch, step_noise=noise)
+    torch.cuda.synchronize()
+    assert den.cluster_status()[0] == 0
+    den.cluster_ms = False
+    _with_cluster(den, 4, 1)
+    ref = torch.cat([den.sample_loop(lat[i:i + 64].contiguous(), cond[i:i + 64].contiguous(), sch,
+                                     step_noise=None if noise is None else noise[:, i:i + 64].contiguous()) for i in range(0, B, 64)], 1)
     torch.cuda.synchronize()
     assert torch.equal(z, ref), float((z - ref).abs().max())
     _with_cluster(den, 0)
