@@ -1097,6 +1097,36 @@ def test_cluster_ms_two_condition_tokens(dev, B, sched):
     assert rel_err(z.cpu().numpy(), one.cpu().numpy()) < 1e-3
 
 
+@pytest.mark.parametrize("ntok", [1, 2])
+def test_cluster_ms_random_shapes(dev, ntok):
+    """A short soak of k_den_cluster_ms (scripts/cluster_ms_soak.py runs thousands): random batch sizes 65 .. 512 (384 with two condition
+    tokens), 3-6 steps, DDIM or DDPM with injected noise, two denoiser objects with their own buffers alternating -- every result
+    bit-identical to k_den_cluster with four CUs per sample on the same samples, and no cluster gives up."""
+    conds = ("text", "scene", "interactee") if ntok == 2 else ("text", "interactee")
+    dens = [make_den(dev, cond=conds, weight_dtype="fp16"), make_den(dev, cond=conds, weight_dtype="fp16")]
+    ref = _with_cluster(make_den(dev, cond=conds, weight_dtype="fp16"), 4, 1)
+    ref.cluster_ms = False
+    rng = np.random.default_rng(77 + ntok)
+    for it in range(24):
+        B = int(rng.integers(65, 513 if ntok == 1 else 385))
+        steps = int(rng.integers(3, 7))
+        kind = "ddpm" if rng.random() < 0.4 else "ddim"
+        sch = _sched(kind)
+        sch.set_timesteps(1000 if kind == "ddpm" else 50)
+        sch.timesteps = sch.timesteps[:steps]
+        g = torch.Generator(device="cpu").manual_seed(500 + it)
+        lat, cond = torch.randn(B, 1, 256, generator=g).to(dev), torch.randn(B, ntok, 256, generator=g).to(dev)
+        noise = torch.randn(steps, B, 256, generator=g).to(dev) if kind == "ddpm" else None
+        den = dens[it % 2]
+        assert den._cluster_plan(B, ntok, False, False) == (4, -(-B // 64))
+        z = den.sample_loop(lat, cond, sch, step_noise=noise)
+        r = torch.cat([ref.sample_loop(lat[i:i + 64].contiguous(), cond[i:i + 64].contiguous(), sch,
+                                       step_noise=None if noise is None else noise[:, i:i + 64].contiguous()) for i in range(0, B, 64)], 1)
+        torch.cuda.synchronize()
+        assert den.cluster_status()[0] == 0 and ref.cluster_status()[0] == 0
+        assert torch.equal(z, r), (it, B, steps, kind, float((z - r).abs().max()))
+
+
 def test_single_forward_stays_off_the_large_batch_kernel(dev):
     """MldDenoiser.forward (one step, no scheduler; mld_denoiser.py:151-244) hands the kernel one table row PER SAMPLE (scalar and vector
     timesteps alike), which k_den_cluster_ms does not take: at a batch size whose sampling loop runs on it, forward() stays on the
