@@ -880,7 +880,7 @@ __device__ __forceinline__ void tail_qkv_rows(const unsigned short* Xh, unsigned
                                               const float* __restrict__ qkv_b, unsigned short* __restrict__ q_out,
                                               uint4* __restrict__ kp_out, uint4* __restrict__ vp_out, int b, int q0, int S, int spv,
                                               BRing<16 / WAVES, PF>& ring_t) {
-    constexpr int ROWS = RW * WAVES, MTL = ROWS / 16, NTL = 16 / WAVES, CW = 256 / WAVES, NT = 64 * WAVES;
+    constexpr int ROWS = RW * WAVES, MTL = ROWS / 16, NTL = 16 / WAVES, CW = 256 / WAVES;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int ldq = 256 + HPAD;
     const size_t base = (size_t)b * S;
