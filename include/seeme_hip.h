@@ -236,8 +236,8 @@ typedef struct {
                                           * (units of ca_block.query / proj_out included, one more exchange per layer) */
     int samples;                         /* 0 / 1: one sample per cluster (k_den_cluster).  2..8: the large-batch form (k_den_cluster_ms,
                                           * csrc/den_cluster_ms.inc.hip): a cluster owns up to `samples` chains that share its weight stream
-                                          * (two MFMA A rows per sample, wave s = epilogue wave of sample s): fp16 image, C = 4 or 8, one
-                                          * or two condition tokens, one table row per step; ceil(B / samples) rounded up to 8 clusters x C <= CUs;
+                                          * (two or four MFMA A rows per sample, wave s = epilogue wave of sample s): fp16 image (C = 4 or 8) or bf16
+                                          * image (C = 4, at most 4 samples), one or two condition tokens, one table row per step; ceil(B / samples) rounded up to 8 clusters x C <= CUs;
                                           * xchg >= seeme_den_cluster_ms_xchg_bytes(B, C, samples) */
 } SeemeDenCluster;
 size_t seeme_den_cluster_xchg_bytes(int B, int C);

@@ -13,13 +13,13 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 NTOK = 2 if os.environ.get("N2") else 1          # N2=1: two condition tokens (scene + interactee)
 CONDS = ("text", "scene", "interactee") if NTOK == 2 else ("text", "interactee")
 rng = np.random.default_rng(2026)
-dens = [make_den(dev, cond=CONDS, weight_dtype="fp16"), make_den(dev, cond=CONDS, weight_dtype="fp16")]
-ref = make_den(dev, cond=CONDS, weight_dtype="fp16")
+dens = [make_den(dev, cond=CONDS, weight_dtype=os.environ.get("WD", "fp16")), make_den(dev, cond=CONDS, weight_dtype=os.environ.get("WD", "fp16"))]
+ref = make_den(dev, cond=CONDS, weight_dtype=os.environ.get("WD", "fp16"))
 ref.cluster_ms = False
 bad = 0
 t0 = time.time()
 for it in range(n_cases):
-    B = int(rng.integers(33, 513))
+    B = int(rng.integers(33, (257 if os.environ.get("WD", "fp16") != "fp16" else (385 if NTOK == 2 else 513))))
     steps = int(rng.integers(3, 9))
     kind = "ddpm" if rng.random() < 0.4 else "ddim"
     sch = _sched(kind); sch.set_timesteps(1000 if kind == "ddpm" else 50); sch.timesteps = sch.timesteps[:steps]

@@ -53,9 +53,17 @@ template <> struct ClmSched<8, false> { static constexpr int PRO = 2; typedef Cl
 template <> struct ClmSched<4, true> { static constexpr int PRO = 4; typedef ClSeq<4, 5> W1A; typedef ClSeq<6, 7> W1B; typedef ClSeq<8, 9> W2A; typedef ClSeq<10> W2B; typedef ClSeq<11> WXA; typedef ClSeq<12> WXB; typedef ClSeq<13, 14> W3; typedef ClSeq<16, 17, 18, 19> AF; };
 template <> struct ClmSched<8, true> { static constexpr int PRO = 2; typedef ClSeq<2, 3> W1A; typedef ClSeq<4> W1B; typedef ClSeq<5> W2A; typedef ClSeq<6> W2B; typedef ClSeq<7> WXA; typedef ClSeq<8> WXB; typedef ClSeq<9, 10> W3; typedef ClSeq<12, 13> AF; };
 
-template <int C, bool Q = false> struct ClM {
+// A rows per sample.  NARROW (fp16 only): two -- (hi, lo) -- so that 8 samples share the 16 rows and a lane group's accumulator rows 4 g .. 4 g + 3 hold
+// two samples; otherwise four -- fp16 (hi, lo, -, -), bf16 (hi, mid, lo, -) -- 4 samples, one per lane group (half the epilogue work per lane: the
+// form used while a cluster owns at most four samples).
+template <typename WT, bool NARROW> struct ClmRows {
+    static_assert(WT::HALF || !NARROW, "the bf16 split has three parts");
+    static constexpr int MS = NARROW ? 8 : 4, SPL = NARROW ? 2 : 1, ROWB = NARROW ? 32 : 64;
+};
+template <typename WT, int C, bool Q = false, bool NARROW = true> struct ClM {
     typedef ClG<C, Q> G;
-    static constexpr int MS = 8;                         // samples per cluster
+    static constexpr int MS = ClmRows<WT, NARROW>::MS;   // samples per cluster
+    static constexpr int SPL = ClmRows<WT, NARROW>::SPL; // samples in a lane group's accumulator rows
     static constexpr int XKB = 1024;                     // bytes per k-block of an A-operand buffer: [k-group 4][row 16][8 halves]
     static constexpr int XBUF = 256 / 32 * XKB / 4;      // floats of a 256-k operand buffer (8 KiB)
     static constexpr int XHK = G::NB > 128 ? G::NB : 128;
@@ -89,25 +97,48 @@ __device__ __forceinline__ ClX clm_xin(const float* buf, int lane) {
     x.kbs = 1024;
     return x;
 }
+template <typename WT, bool NARROW>
 __device__ __forceinline__ void clm_put1(float* buf, int s, int k, float v) {
-    char* dst = reinterpret_cast<char*>(buf) + (k >> 5) * 1024 + ((k >> 3) & 3) * 256 + s * 32 + (k & 7) * 2;
-    const _Float16 hi = (_Float16)v;
-    *reinterpret_cast<_Float16*>(dst) = hi;
-    *reinterpret_cast<_Float16*>(dst + 16) = (_Float16)((v - (float)hi) * DEN_F16_LO_SCALE);
+    char* dst = reinterpret_cast<char*>(buf) + (k >> 5) * 1024 + ((k >> 3) & 3) * 256 + s * ClmRows<WT, NARROW>::ROWB + (k & 7) * 2;
+    if constexpr (WT::HALF) {
+        const _Float16 hi = (_Float16)v;
+        *reinterpret_cast<_Float16*>(dst) = hi;
+        *reinterpret_cast<_Float16*>(dst + 16) = (_Float16)((v - (float)hi) * DEN_F16_LO_SCALE);
+    } else {
+        const __bf16 hi = (__bf16)v; const float r1 = v - (float)hi; const __bf16 mid = (__bf16)r1;
+        *reinterpret_cast<__bf16*>(dst) = hi;
+        *reinterpret_cast<__bf16*>(dst + 16) = mid;
+        *reinterpret_cast<__bf16*>(dst + 32) = (__bf16)(r1 - (float)mid);
+    }
 }
+template <typename WT, bool NARROW>
 __device__ __forceinline__ void clm_put4(float* buf, int s, int lane, float4 v) {      // values k = 4 lane .. 4 lane + 3 of sample s
     const int k = 4 * lane;
-    char* dst = reinterpret_cast<char*>(buf) + (k >> 5) * 1024 + ((k >> 3) & 3) * 256 + s * 32 + (k & 7) * 2;
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    const h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-    const h4 lo = {(_Float16)((v.x - (float)hi.x) * DEN_F16_LO_SCALE), (_Float16)((v.y - (float)hi.y) * DEN_F16_LO_SCALE),
-                   (_Float16)((v.z - (float)hi.z) * DEN_F16_LO_SCALE), (_Float16)((v.w - (float)hi.w) * DEN_F16_LO_SCALE)};
-    *reinterpret_cast<h4*>(dst) = hi;
-    *reinterpret_cast<h4*>(dst + 16) = lo;
+    char* dst = reinterpret_cast<char*>(buf) + (k >> 5) * 1024 + ((k >> 3) & 3) * 256 + s * ClmRows<WT, NARROW>::ROWB + (k & 7) * 2;
+    if constexpr (WT::HALF) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        const h4 lo = {(_Float16)((v.x - (float)hi.x) * DEN_F16_LO_SCALE), (_Float16)((v.y - (float)hi.y) * DEN_F16_LO_SCALE),
+                       (_Float16)((v.z - (float)hi.z) * DEN_F16_LO_SCALE), (_Float16)((v.w - (float)hi.w) * DEN_F16_LO_SCALE)};
+        *reinterpret_cast<h4*>(dst) = hi;
+        *reinterpret_cast<h4*>(dst + 16) = lo;
+    } else {
+        typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+        const b4 hi = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        const float4 r1 = make_float4(v.x - (float)hi.x, v.y - (float)hi.y, v.z - (float)hi.z, v.w - (float)hi.w);
+        const b4 mid = {(__bf16)r1.x, (__bf16)r1.y, (__bf16)r1.z, (__bf16)r1.w};
+        const b4 lo = {(__bf16)(r1.x - (float)mid.x), (__bf16)(r1.y - (float)mid.y), (__bf16)(r1.z - (float)mid.z), (__bf16)(r1.w - (float)mid.w)};
+        *reinterpret_cast<b4*>(dst) = hi;
+        *reinterpret_cast<b4*>(dst + 16) = mid;
+        *reinterpret_cast<b4*>(dst + 32) = lo;
+    }
 }
-// the two samples of a lane's accumulator: lane group g = lane >> 4 holds D rows 4 g .. 4 g + 3 = (hi, lo) of samples 2 g and 2 g + 1
+// the samples of a lane's accumulator: lane group g = lane >> 4 holds D rows 4 g .. 4 g + 3 = fp16: (hi, lo) of samples 2 g and 2 g + 1;
+// bf16: (hi, mid, lo, -) of sample g
+template <typename WT, bool NARROW>
 __device__ __forceinline__ float clm_out(const f32x4& a, int j) {
-    return j ? fmaf(a.w, 1.f / DEN_F16_LO_SCALE, a.z) : fmaf(a.y, 1.f / DEN_F16_LO_SCALE, a.x);
+    if constexpr (WT::HALF) return (NARROW && j) ? fmaf(a.w, 1.f / DEN_F16_LO_SCALE, a.z) : fmaf(a.y, 1.f / DEN_F16_LO_SCALE, a.x);
+    else return a.x + (a.y + a.z);
 }
 
 // FLG[2] counts the samples whose epilogue wave has published its part of an exchange (ever: nact per exchange).  A window's requests go out
@@ -126,12 +157,12 @@ __device__ __forceinline__ void clm_published(int* f, int lane, int target) {
 
 // one piece (<= 1 KiB) of the NEXT layer's operands per wave and phase k = 0 .. 5: requested at the top of the phase, stored to the other
 // half of the staging buffer at its end (k_den_cluster's ClStage, with the compact destination layout and MS samples' rows)
-template <int C, bool Q>
+template <typename WT, int C, bool Q, bool NARROW>
 struct ClmStage {
     float4 r; int dst, n4;
     __device__ __forceinline__ void load(int k, int wave, int lane, const float* __restrict__ vpg, const DenLayerOff* __restrict__ L,
                                          const float* __restrict__ tt_row, int l, const SeemeSampleArgs& A, int b0, int nact, int c) {
-        typedef ClM<C, Q> M; typedef ClG<C, Q> G;
+        typedef ClM<WT, C, Q, NARROW> M; typedef ClG<C, Q> G;
         const float* vb = vpg + L->skip_b;
         const int i = wave + 8 * k;
         const float* src = vb; int d = 0, n = 0;
@@ -189,11 +220,11 @@ struct ClmStage {
     }
 };
 
-template <int C, bool Q>
+template <typename WT, int C, bool Q, bool NARROW>
 __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    typedef WF16 WT;
-    typedef ClW<WT> W; typedef ClG<C, Q> G; typedef ClM<C, Q> M;
+    typedef ClW<WT> W; typedef ClG<C, Q> G; typedef ClM<WT, C, Q, NARROW> M;
+    constexpr int SPL = M::SPL;
     constexpr int MS = M::MS;
     constexpr int N = Q ? 2 : 1;                 // condition tokens
     constexpr int NT = N + 2;                    // score slots: self, condition token(s), time
@@ -218,7 +249,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
     const int bs = b0 + (epi ? es : 0);
     const int ca_R = A.steps;                                    // (one table row per step: trow_per_sample stays on the other kernels)
     const bool sentinel = ka.spc >= DCLM_SENTINEL_FROM;
-    const int g2 = (lane >> 4) * 2;                              // this lane's accumulators hold samples g2 and g2 + 1
+    const int g2 = (lane >> 4) * SPL;                            // this lane's accumulators hold samples g2 .. g2 + SPL - 1
 
     float* CONSTV = smem;                        // [768]  query_pos.pe[0], encoder.norm.{weight,bias}
     float* KEEP = CONSTV + 768;                  // [MS][256] the latents
@@ -260,7 +291,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
     for (int i = tid; i < 192; i += DEN_THREADS)
         st4(CONSTV + 4 * i, i < 64 ? ld4(vp + lay->pe0 + 4 * i) : (i < 128 ? ld4(vp + lay->fnw + 4 * (i - 64)) : ld4(vp + lay->fnb + 4 * (i - 128))));
     {
-        ClmStage<C, Q> p;
+        ClmStage<WT, C, Q, NARROW> p;
 #pragma unroll 1
         for (int k = 0; k < M::NPH; ++k) {
             p.load(k, wave, lane, vp, &lay->L[0], A.ttab + (size_t)row * SEEME_TROW, 0, A, b0, nact, c);
@@ -292,7 +323,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
     if (epi) {
         st4(KEEP + es * 256 + 4 * lane, xr);
         xr = f4_add(xr, ld4(CONSTV + 4 * lane));                // sample + query_pos (mld_denoiser.py:210)
-        clm_put4(XA, es, lane, xr);
+        clm_put4<WT, NARROW>(XA, es, lane, xr);
         st4(RES + es * 256 + 4 * lane, xr);
     }
     ClRing<WT> ring;
@@ -328,7 +359,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
             const unsigned e1 = 1u + (unsigned)G::EPL * (unsigned)(step * SEEME_DEN_NL + l), e2 = e1 + 1u, e3 = e1 + 2u;
             const int pub1 = nact * (int)e1, pub2 = nact * (int)e2, pub3 = nact * (int)e3;   // the LDS count of published samples after X1 / X2 / X3 of this layer (FLG[2])
             (void)e3; (void)pub3;
-            ClmStage<C, Q> nxt;
+            ClmStage<WT, C, Q, NARROW> nxt;
             const float* const tt_next = A.ttab + (size_t)(ln == 0 ? row_next : row) * SEEME_TROW;
 
             // ================= A: in_proj' (+ folded skip linear), column-split by dims =================
@@ -348,10 +379,10 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                     for (int t = 0; t < G::TA; ++t) {
                         const int T = wave * G::TA + t, part = T / (G::S / 16), d = (T % (G::S / 16)) * 16 + col;
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
+                        for (int j = 0; j < SPL; ++j) {
                             const int sj = g2 + j;
                             if (sj < nact) {
-                                const float val = clm_out(acc[t], j);
+                                const float val = clm_out<WT, NARROW>(acc[t], j);
                                 unsigned long long* const xs_ = xg0 + (size_t)sj * G::G_TOTAL + G::G_X1 + c * G::X1_G;
                                 if (part == 0) QS[sj * G::S + d] = val + VP[M::O_INB + d];
                                 else if (part == 1) KS[sj * G::S + d] = val + VP[M::O_INB + G::S + d];
@@ -453,7 +484,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 att = f4_fma(sc[NT - 1] * inv, ld4(VP + M::O_TV + 4 * lane), att);
                 if (skip) xr = make_float4(__uint_as_float(gy0.x), __uint_as_float(gy0.z), __uint_as_float(gy1.x), __uint_as_float(gy1.z));
                 xr = wave_ln(f4_add(xr, att), VP + M::O_N1W, VP + M::O_N1B, lane);        // the "values" carry out_proj: residual + norm1
-                clm_put4(XB, es, lane, xr);
+                clm_put4<WT, NARROW>(XB, es, lane, xr);
             } else if constexpr (WIN) {        // (waves without a sample: their eighth of both windows -- behind sample 0's publish and sweep, as in
                                                //  k_den_cluster: requested at once they would stand in front of the epilogue waves' granule stores)
                 if (DCLM_IDLE_FLAGS) clm_wait_published(FLG + 2, pub1);
@@ -475,8 +506,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                     const int jh = (wave * G::TB + t) * 16 + col;
                     const float bh = VP[M::O_L1B + jh];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        if (g2 + j < nact) clm_put1(XH, g2 + j, jh, fmaxf(clm_out(acc[t], j) + bh, 0.f));
+                    for (int j = 0; j < SPL; ++j)
+                        if (g2 + j < nact) clm_put1<WT, NARROW>(XH, g2 + j, jh, fmaxf(clm_out<WT, NARROW>(acc[t], j) + bh, 0.f));
                 }
             }
             nxt.store(lane, STGN);
@@ -492,8 +523,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 for (int tt = 0; tt < 2; ++tt) {
                     const int n = (2 * wave + tt) * 16 + col;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        if (g2 + j < nact) cl_store_granule(xg0 + (size_t)(g2 + j) * G::G_TOTAL + G::G_X2 + c * 256 + n, e2, clm_out(acc[tt], j), local);
+                    for (int j = 0; j < SPL; ++j)
+                        if (g2 + j < nact) cl_store_granule(xg0 + (size_t)(g2 + j) * G::G_TOTAL + G::G_X2 + c * 256 + n, e2, clm_out<WT, NARROW>(acc[tt], j), local);
                 }
             }
             if constexpr (Q) nxt.store(lane, STGN);
@@ -541,9 +572,9 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 xr = wave_ln(f4_add(xr, f4_add(sum, ld4(VP + M::O_L2B + 4 * lane))), VP + M::O_N2W, VP + M::O_N2B, lane);
                 if constexpr (!Q) {
                     xr = f4_add(xr, cadd);
-                    clm_put4(XA, es, lane, xr);
+                    clm_put4<WT, NARROW>(XA, es, lane, xr);
                 } else {
-                    clm_put4(XB, es, lane, wave_ln(xr, VP + M::O_CNW, VP + M::O_CNB, lane));   // ca_block.norm -> input of the query (mdiff_transformer.py:229)
+                    clm_put4<WT, NARROW>(XB, es, lane, wave_ln(xr, VP + M::O_CNW, VP + M::O_CNB, lane));   // ca_block.norm -> input of the query (mdiff_transformer.py:229)
                 }
                 st4(RES + es * 256 + 4 * lane, xr);
             } else if constexpr (WIN) {
@@ -564,8 +595,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                     if (act) {
                         const float bq = VP[M::O_CAQB + wave * 16 + col];
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            if (g2 + j < nact) QS[(g2 + j) * G::S + wave * 16 + col] = clm_out(acc[0], j) + bq;
+                        for (int j = 0; j < SPL; ++j)
+                            if (g2 + j < nact) QS[(g2 + j) * G::S + wave * 16 + col] = clm_out<WT, NARROW>(acc[0], j) + bq;
                     }
                 }
                 __syncthreads(); DEN_DBG(0);
@@ -650,7 +681,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                     }
                     // StylizationBlock (mdiff_transformer.py:152-163): SiLU(LN(y) (1 + scale) + shift) -> proj_out.out_layers
                     const float4 hh = f4_adaln(wave_ln(y, VP + M::O_CSNW, VP + M::O_CSNB, lane), ld4(VP + M::O_CSC + 4 * lane), ld4(VP + M::O_CSH + 4 * lane));
-                    clm_put4(XB, es, lane, f4_silu(hh));
+                    clm_put4<WT, NARROW>(XB, es, lane, f4_silu(hh));
                 } else {
                     if (DCLM_IDLE_FLAGS) clm_wait_published(FLG + 2, pub3);
                     cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::WXA{});
@@ -669,12 +700,12 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                         const int n = (2 * wave + tt) * 16 + col;
                         const float bo = VP[M::O_CAOB + n];
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
+                        for (int j = 0; j < SPL; ++j) {
                             const int sj = g2 + j;
                             if (sj < nact) {
-                                const float x3 = RES[sj * 256 + n] + clm_out(acc[tt], j) + bo;
+                                const float x3 = RES[sj * 256 + n] + clm_out<WT, NARROW>(acc[tt], j) + bo;
                                 RES[sj * 256 + n] = x3;
-                                clm_put1(XA, sj, n, x3);
+                                clm_put1<WT, NARROW>(XA, sj, n, x3);
                             }
                         }
                     }
@@ -693,8 +724,8 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                 const int jh = wave * 16 + col;
                 const float bh = VP[M::O_F1B + jh];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if (g2 + j < nact) clm_put1(XH, g2 + j, jh, fast_gelu(clm_out(acc[0], j) + bh));
+                for (int j = 0; j < SPL; ++j)
+                    if (g2 + j < nact) clm_put1<WT, NARROW>(XH, g2 + j, jh, fast_gelu(clm_out<WT, NARROW>(acc[0], j) + bh));
             }
             nxt.store(lane, STGN);
             __syncthreads(); DEN_DBG(0);
@@ -706,15 +737,15 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        if (g2 + j < nact) PART[(g2 + j) * 256 + (2 * wave + tt) * 16 + col] = clm_out(acc[tt], j);
+                    for (int j = 0; j < SPL; ++j)
+                        if (g2 + j < nact) PART[(g2 + j) * 256 + (2 * wave + tt) * 16 + col] = clm_out<WT, NARROW>(acc[tt], j);
             }
             __syncthreads(); DEN_DBG(0);
             if constexpr (WIN) cl_issue_seq<WT, C, Q>(ring, wave, voff, wg, bc, bn, skip, nskip, typename SCH::W3{});
             if (epi) {
                 const float4 y2 = f4_add(ld4(PART + es * 256 + 4 * lane), ld4(VP + M::O_F2B + 4 * lane));
                 const float4 hh = f4_adaln(wave_ln(y2, VP + M::O_FSNW, VP + M::O_FSNB, lane), ld4(VP + M::O_TSC + 4 * lane), ld4(VP + M::O_TSH + 4 * lane));
-                clm_put4(XB, es, lane, f4_silu(hh));
+                clm_put4<WT, NARROW>(XB, es, lane, f4_silu(hh));
             }
             __syncthreads(); DEN_DBG(0);
             // ================= F: ffn.proj_out.out_layers + residual (replicated); writes the next layer's input =================
@@ -729,13 +760,13 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                     const int n = (2 * wave + tt) * 16 + col;
                     const float bo = VP[M::O_FOB + n];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < SPL; ++j) {
                         const int sj = g2 + j;
                         if (sj < nact) {
-                            const float xn = RES[sj * 256 + n] + clm_out(acc[tt], j) + bo;
+                            const float xn = RES[sj * 256 + n] + clm_out<WT, NARROW>(acc[tt], j) + bo;
                             RES[sj * 256 + n] = xn;
-                            clm_put1(XA, sj, n, xn);
-                            if (l < 2) clm_put1(SKF + M::XBUF * l, sj, n, xn);          // xs.append(x) (cross_attention.py:70-72)
+                            clm_put1<WT, NARROW>(XA, sj, n, xn);
+                            if (l < 2) clm_put1<WT, NARROW>(SKF + M::XBUF * l, sj, n, xn);          // xs.append(x) (cross_attention.py:70-72)
                         }
                     }
                 }
@@ -770,7 +801,7 @@ __global__ __launch_bounds__(DEN_THREADS) void k_den_cluster_ms(const ClArgs ka)
                         const float4 nl = make_float4(o[0], o[1], o[2], o[3]);
                         st4(KEEP + es * 256 + 4 * lane, nl);
                         xr = f4_add(nl, ld4(CONSTV + 4 * lane));
-                        clm_put4(XA, es, lane, xr);
+                        clm_put4<WT, NARROW>(XA, es, lane, xr);
                         st4(RES + es * 256 + 4 * lane, xr);
                     }
                 }
@@ -795,7 +826,7 @@ extern "C" size_t seeme_den_cluster_ms_xchg_bytes(int B, int C, int spc) {      
     return DCL_HDR_BYTES + (size_t)clm_clusters(B, spc) * 8 * per * 8;
 }
 
-template <int C, bool Q>
+template <typename WT, int C, bool Q, bool NARROW>
 static int launch_den_cluster_ms(const ClArgs& ka0, hipStream_t st) {
     ClArgs ka = ka0;
     ka.clusters = clm_clusters(ka.s.B, ka.spc);
@@ -804,23 +835,30 @@ static int launch_den_cluster_ms(const ClArgs& ka0, hipStream_t st) {
     SEEME_HIP(hipGetDevice(&dev));
     SEEME_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (grid > cus || grid > 256) return seeme_fail("denoiser_sample_cluster: clusters x C exceeds one workgroup per CU of this device");
-    const size_t lds = (size_t)ClM<C, Q>::LDS_FLOATS * sizeof(float);
+    if (ka0.spc > ClM<WT, C, Q, NARROW>::MS) return seeme_fail("denoiser_sample_cluster: at most 8 (fp16) / 4 (bf16) samples per cluster");
+    const size_t lds = (size_t)ClM<WT, C, Q, NARROW>::LDS_FLOATS * sizeof(float);
     if (lds > 160 * 1024 || lds <= 80 * 1024) return seeme_fail("denoiser_sample_cluster: LDS footprint must force one workgroup per CU");
-    SEEME_HIP(hipFuncSetAttribute((const void*)k_den_cluster_ms<C, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SEEME_HIP(hipFuncSetAttribute((const void*)k_den_cluster_ms<WT, C, Q, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SEEME_HIP(hipMemsetAsync(ka.hdr, 0, seeme_den_cluster_ms_xchg_bytes(ka.s.B, C, ka.spc), st));
-    hipLaunchKernelGGL((k_den_cluster_ms<C, Q>), dim3(grid), dim3(DEN_THREADS), lds, st, ka);
+    hipLaunchKernelGGL((k_den_cluster_ms<WT, C, Q, NARROW>), dim3(grid), dim3(DEN_THREADS), lds, st, ka);
     return seeme_check_launch("k_den_cluster_ms");
 }
 
 // called by seeme_denoiser_sample_cluster when SeemeDenCluster.samples > 1
 static int den_cluster_ms_dispatch(const SeemeDenoiserWeights* w, const SeemeDenCluster* cl, const SeemeSampleArgs* a, ClArgs& ka, hipStream_t st) {
-    if (cl->wdtype != 2) return seeme_fail("denoiser_sample_cluster: several samples per cluster need the fp16 weight image");
+    if (cl->wdtype != 2 && cl->wdtype != 1) return seeme_fail("denoiser_sample_cluster: several samples per cluster need a 16-bit weight image");
     if (cl->C != 4 && cl->C != 8) return seeme_fail("denoiser_sample_cluster: several samples per cluster need C = 4 or 8");
     if (cl->samples > 8) return seeme_fail("denoiser_sample_cluster: at most 8 samples per cluster");
     if (a->N != 1 && a->N != 2) return seeme_fail("denoiser_sample_cluster: several samples per cluster need one or two condition tokens");
     if (a->trow_per_sample) return seeme_fail("denoiser_sample_cluster: several samples per cluster share the step's table row");
     if (cl->xchg_bytes < seeme_den_cluster_ms_xchg_bytes(a->B, cl->C, cl->samples)) return seeme_fail("denoiser_sample_cluster: exchange buffer too small");
     ka.spc = cl->samples;
-    if (a->N == 2) return cl->C == 8 ? launch_den_cluster_ms<8, true>(ka, st) : launch_den_cluster_ms<4, true>(ka, st);
-    return cl->C == 8 ? launch_den_cluster_ms<8, false>(ka, st) : launch_den_cluster_ms<4, false>(ka, st);
+    if (cl->wdtype == 1) {      // bf16 image: four A rows per sample, up to 4 samples per cluster (4-CU clusters only)
+        if (cl->C != 4) return seeme_fail("denoiser_sample_cluster: the bf16 image takes several samples per cluster at C = 4 only");
+        return a->N == 2 ? launch_den_cluster_ms<WBF16, 4, true, false>(ka, st) : launch_den_cluster_ms<WBF16, 4, false, false>(ka, st);
+    }
+    if (cl->C == 4 && cl->samples <= 4)      // fp16, at most four samples per cluster: four A rows per sample, one sample per lane group
+        return a->N == 2 ? launch_den_cluster_ms<WF16, 4, true, false>(ka, st) : launch_den_cluster_ms<WF16, 4, false, false>(ka, st);
+    if (a->N == 2) return cl->C == 8 ? launch_den_cluster_ms<WF16, 8, true, true>(ka, st) : launch_den_cluster_ms<WF16, 4, true, true>(ka, st);
+    return cl->C == 8 ? launch_den_cluster_ms<WF16, 8, false, true>(ka, st) : launch_den_cluster_ms<WF16, 4, false, true>(ka, st);
 }

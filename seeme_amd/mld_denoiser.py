@@ -392,7 +392,7 @@ class MldDenoiser(nn.Module):
 
     def _cluster_plan(self, B: int, N: int, cfg: bool, per_sample: bool, cus: int = 256):
         """(CUs per cluster, samples per cluster) of this launch; (0, 1) = the one-CU-per-sample kernel.  Up to 64 samples a cluster owns
-        ONE sample (k_den_cluster, windowed schedules: 8 CUs up to B = 32, 4 up to 64); above that -- fp16 image, one condition token,
+        ONE sample (k_den_cluster, windowed schedules: 8 CUs up to B = 32, 4 up to 64); above that -- 16-bit image, one or two condition tokens,
         one table row per step -- the large-batch form k_den_cluster_ms: 64 clusters of 4 CUs that own ceil(B / 64) <= 8 samples each
         (B <= 512; with two condition tokens up to 6 samples, B <= 384: 5.14 -> 4.09 ms at B = 128, 5.35 -> 4.54 at 256, none at 512).  Measured at 50 DDIM steps (profiles/r03_g_cluster_ms.txt, r03_k_c4_windows.txt): B = 64 2.83 ms (8 CUs x 2 samples
         3.09), B = 128 3.44 against 4.30 (2 CUs per sample) / 4.46 (one), B = 256 3.66 against 4.70, B = 512 4.37 against 4.92;
@@ -402,7 +402,7 @@ class MldDenoiser(nn.Module):
         want = self.cluster if want is None else (want if want == "auto" else int(want))
         ms = os.environ.get("SEEME_DEN_CLUSTER_MS", "1") != "0" and self.cluster_ms
         if (want != "auto" or not ms or B <= 32 or N not in (1, 2) or cfg or per_sample or self.num_heads != 1
-                or self.weight_dtype != "fp16"):
+                or self.weight_dtype not in ("fp16", "bf16")):
             return Cc, 1
         forced = os.environ.get("SEEME_DEN_CLUSTER_MS_PLAN")           # "C,samples" (samples >= 2): measurement only
         if forced:
@@ -412,7 +412,8 @@ class MldDenoiser(nn.Module):
         if B <= 64 and Cc == 4:
             return Cc, 1
         ncl = (cus // 4) // 8 * 8
-        if ncl >= 8 and -(-B // ncl) <= (8 if N == 1 else 6):       # (two condition tokens: no gain left at 7 or 8 samples per cluster)
+        most = 4 if self.weight_dtype == "bf16" else (8 if N == 1 else 6)   # bf16: four A rows per sample; two condition tokens: no gain left at 7, 8
+        if ncl >= 8 and -(-B // ncl) <= most:
             return 4, max(2, -(-B // ncl))
         return Cc, 1
 

@@ -1028,6 +1028,9 @@ def test_auto_cluster_policy(dev):
     assert d16._cluster_plan(128, 1, False, True) == (2, 1)
     d16.cluster_ms = False
     assert d16._cluster_plan(128, 1, False, False) == (2, 1)
+    # the bf16 image: four A rows per sample, up to four samples per cluster (B <= 256)
+    db = make_den(dev, weight_dtype="bf16")
+    assert [db._cluster_plan(B, 1, False, False) for B in (64, 65, 256, 257)] == [(4, 1), (4, 2), (4, 4), (0, 1)]
 
 
 @pytest.mark.parametrize("B,sched", [(50, "ddim8"), (100, "ddim"), (130, "ddpm"), (512, "ddim")])
@@ -1097,18 +1100,18 @@ def test_cluster_ms_two_condition_tokens(dev, B, sched):
     assert rel_err(z.cpu().numpy(), one.cpu().numpy()) < 1e-3
 
 
-@pytest.mark.parametrize("ntok", [1, 2])
-def test_cluster_ms_random_shapes(dev, ntok):
+@pytest.mark.parametrize("ntok,wd", [(1, "fp16"), (2, "fp16"), (1, "bf16"), (2, "bf16")])
+def test_cluster_ms_random_shapes(dev, ntok, wd):
     """A short soak of k_den_cluster_ms (scripts/cluster_ms_soak.py runs thousands): random batch sizes 65 .. 512 (384 with two condition
-    tokens), 3-6 steps, DDIM or DDPM with injected noise, two denoiser objects with their own buffers alternating -- every result
+    tokens, 256 with the bf16 image: four A rows per sample), 3-6 steps, DDIM or DDPM with injected noise, two denoiser objects with their own buffers alternating -- every result
     bit-identical to k_den_cluster with four CUs per sample on the same samples, and no cluster gives up."""
     conds = ("text", "scene", "interactee") if ntok == 2 else ("text", "interactee")
-    dens = [make_den(dev, cond=conds, weight_dtype="fp16"), make_den(dev, cond=conds, weight_dtype="fp16")]
-    ref = _with_cluster(make_den(dev, cond=conds, weight_dtype="fp16"), 4, 1)
+    dens = [make_den(dev, cond=conds, weight_dtype=wd), make_den(dev, cond=conds, weight_dtype=wd)]
+    ref = _with_cluster(make_den(dev, cond=conds, weight_dtype=wd), 4, 1)
     ref.cluster_ms = False
     rng = np.random.default_rng(77 + ntok)
     for it in range(24):
-        B = int(rng.integers(65, 513 if ntok == 1 else 385))
+        B = int(rng.integers(65, 257 if wd == "bf16" else (513 if ntok == 1 else 385)))
         steps = int(rng.integers(3, 7))
         kind = "ddpm" if rng.random() < 0.4 else "ddim"
         sch = _sched(kind)
